@@ -1,0 +1,13 @@
+// Line factorizations used by the pruned pipeline (padded length L = 2n).
+#pragma once
+#include "fft_core.hpp"
+namespace lsfc { namespace fft {
+//                L    T   R0  R1  R2
+using Cfg32   = Cfg<32,   4,  8,  4>;
+using Cfg64   = Cfg<64,   8,  8,  8>;
+using Cfg128  = Cfg<128, 16,  8,  4, 4>;
+using Cfg256  = Cfg<256, 32,  8,  8, 4>;
+using Cfg512  = Cfg<512, 64,  8,  8, 8>;
+using Cfg1024 = Cfg<1024, 64, 16, 8, 8>;
+using Cfg2048 = Cfg<2048, 128, 16, 16, 8>;
+}} // namespace

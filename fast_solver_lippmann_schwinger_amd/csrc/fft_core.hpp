@@ -1,0 +1,294 @@
+// Hand-written fp64 complex FFT building blocks for gfx950 (wave64, LDS exchange).
+//
+// One transform line of length L is spread over T threads, E = L/T elements per
+// thread held in registers.  The forward transform is a decimation-in-frequency
+// Cooley-Tukey factorisation L = R0*R1(*R2) computed IN PLACE: stage s works on
+// sub-blocks of length LS_s with radix R_s; between stages the threads swap
+// elements through LDS.  Outputs are left in digit-reversed ("storage") order;
+// the inverse transform runs the same stages backwards (conjugate twiddle, then
+// conjugate butterfly) and therefore consumes exactly that order.  Frequency
+// indices are only labels for the convolution: the Green's symbol is permuted
+// once at plan creation (see perm_table), so no reordering pass ever runs.
+//
+// Register slot e of thread t corresponds to
+//   time side      : position  t + T*e                      (natural order)
+//   frequency side : storage index s = t + T*e, frequency = perm_table[s]
+// so zero padding (positions >= L/2 are zero) and cropping (only positions
+// < L/2 are wanted) both mean "slots e >= E/2", which lets the first forward /
+// last inverse butterfly drop one radix-2 level (PRUNE).
+#pragma once
+#ifndef LSFC_FFT_HOST_EMULATION      // tests/emu/ compiles this header with g++ to check the index algebra
+#include <hip/hip_runtime.h>
+#define LSFC_BARRIER() __syncthreads()
+#endif
+#include <utility>
+
+namespace lsfc { namespace fft {
+
+using cplx = double2;
+
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return make_double2(fma(-a.y, b.y, a.x * b.x), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
+
+// exp(-DIR * 2*pi*i * K / R) * a for compile-time K, R in {2,4,8,16}.
+template <int R, int K, int DIR> struct MulW {
+    __device__ __forceinline__ static cplx apply(cplx a) {
+        constexpr int idx = ((K * (16 / R)) % 16 + 16) % 16;
+        constexpr double C16[16] = { 1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
+                                     0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848,
+                                    -1.0, -0.92387953251128673848, -0.70710678118654752440, -0.38268343236508977173,
+                                     0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848 };
+        constexpr double S16[16] = { 0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
+                                     1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
+                                     0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848,
+                                    -1.0, -0.92387953251128673848, -0.70710678118654752440, -0.38268343236508977173 };
+        if constexpr (idx == 0) return a;
+        else if constexpr (idx == 8) return make_double2(-a.x, -a.y);
+        else if constexpr (idx == 4) return DIR > 0 ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x);
+        else if constexpr (idx == 12) return DIR > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+        else if constexpr (idx == 2) {
+            constexpr double c = 0.70710678118654752440;
+            return DIR > 0 ? make_double2((a.x + a.y) * c, (a.y - a.x) * c) : make_double2((a.x - a.y) * c, (a.x + a.y) * c);
+        } else if constexpr (idx == 6) {
+            constexpr double c = 0.70710678118654752440;
+            return DIR > 0 ? make_double2((a.y - a.x) * c, -(a.x + a.y) * c) : make_double2(-(a.x + a.y) * c, (a.x - a.y) * c);
+        } else {
+            constexpr double wr = C16[idx];
+            constexpr double wi = (DIR > 0 ? -1.0 : 1.0) * S16[idx];
+            return make_double2(fma(-a.y, wi, a.x * wr), fma(a.x, wi, a.y * wr));
+        }
+    }
+};
+
+// In-register DFT of size R (natural order in, natural order out).
+// DIR=+1: X[k] = sum_j a[j] exp(-2 pi i jk/R);  DIR=-1: conjugate kernel (unnormalised).
+template <int R, int DIR> struct Dft;
+
+template <int DIR> struct Dft<1, DIR> { __device__ __forceinline__ static void run(cplx (&)[1]) {} };
+template <int DIR> struct Dft<2, DIR> {
+    __device__ __forceinline__ static void run(cplx (&a)[2]) {
+        const cplx s = cadd(a[0], a[1]), d = csub(a[0], a[1]); a[0] = s; a[1] = d;
+    }
+};
+
+template <int R, int DIR, int... K>
+__device__ __forceinline__ void dit_combine(cplx (&a)[R], const cplx (&ev)[R / 2], const cplx (&od)[R / 2],
+                                            std::integer_sequence<int, K...>) {
+    (([&] { const cplx t = MulW<R, K, DIR>::apply(od[K]); a[K] = cadd(ev[K], t); a[K + R / 2] = csub(ev[K], t); }()), ...);
+}
+
+template <int R, int DIR> struct Dft {
+    __device__ __forceinline__ static void run(cplx (&a)[R]) {
+        cplx ev[R / 2], od[R / 2];
+#pragma unroll
+        for (int j = 0; j < R / 2; ++j) { ev[j] = a[2 * j]; od[j] = a[2 * j + 1]; }
+        Dft<R / 2, DIR>::run(ev);
+        Dft<R / 2, DIR>::run(od);
+        dit_combine<R, DIR>(a, ev, od, std::make_integer_sequence<int, R / 2>{});
+    }
+};
+
+// Forward DFT whose inputs a[R/2..R) are zero (zero-padded line): one DIF level
+// degenerates to a twiddle, X[2k] = DFT_{R/2}(a)[k], X[2k+1] = DFT_{R/2}(a.*W_R^j)[k].
+template <int R, int DIR, int... J>
+__device__ __forceinline__ void halfzero_twiddle(cplx (&od)[R / 2], const cplx (&a)[R], std::integer_sequence<int, J...>) {
+    ((od[J] = MulW<R, J, DIR>::apply(a[J])), ...);
+}
+template <int R, int DIR>
+__device__ __forceinline__ void dft_halfzero(cplx (&a)[R]) {
+    if constexpr (R == 2) { a[1] = a[0]; }
+    else {
+        cplx ev[R / 2], od[R / 2];
+#pragma unroll
+        for (int j = 0; j < R / 2; ++j) ev[j] = a[j];
+        halfzero_twiddle<R, DIR>(od, a, std::make_integer_sequence<int, R / 2>{});
+        Dft<R / 2, DIR>::run(ev);
+        Dft<R / 2, DIR>::run(od);
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) { a[2 * k] = ev[k]; a[2 * k + 1] = od[k]; }
+    }
+}
+
+// DFT of which only outputs [0, R/2) are wanted (cropped line): the last DIT level
+// computes only the "+" halves.  Outputs [R/2, R) are left unspecified.
+template <int R, int DIR, int... K>
+__device__ __forceinline__ void halfout_combine(cplx (&a)[R], const cplx (&ev)[R / 2], const cplx (&od)[R / 2],
+                                                std::integer_sequence<int, K...>) {
+    ((a[K] = cadd(ev[K], MulW<R, K, DIR>::apply(od[K]))), ...);
+}
+template <int R, int DIR>
+__device__ __forceinline__ void dft_halfout(cplx (&a)[R]) {
+    if constexpr (R == 2) { a[0] = cadd(a[0], a[1]); }
+    else {
+        cplx ev[R / 2], od[R / 2];
+#pragma unroll
+        for (int j = 0; j < R / 2; ++j) { ev[j] = a[2 * j]; od[j] = a[2 * j + 1]; }
+        Dft<R / 2, DIR>::run(ev);
+        Dft<R / 2, DIR>::run(od);
+        halfout_combine<R, DIR>(a, ev, od, std::make_integer_sequence<int, R / 2>{});
+    }
+}
+
+// w[k] = w1^k for k = 1..R-1 by a depth-<=4 product tree (error ~ 4 ulp).
+template <int R> __device__ __forceinline__ void twiddle_powers(cplx w1, cplx (&w)[R]) {
+    w[0] = make_double2(1.0, 0.0);
+    if constexpr (R > 1) w[1] = w1;
+    if constexpr (R > 2) { w[2] = cmul(w1, w1); w[3] = cmul(w[2], w1); }
+    if constexpr (R > 4) { w[4] = cmul(w[2], w[2]); w[5] = cmul(w[4], w1); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]); }
+    if constexpr (R > 8) {
+        w[8] = cmul(w[4], w[4]);
+#pragma unroll
+        for (int k = 9; k < 16; ++k) w[k] = cmul(w[8], w[k - 8]);
+    }
+}
+
+// Factorisation of one line.
+template <int L_, int T_, int R0_, int R1_, int R2_ = 1> struct Cfg {
+    static constexpr int L = L_, T = T_, E = L_ / T_;
+    static constexpr int R0 = R0_, R1 = R1_, R2 = R2_;
+    static constexpr int NS = (R2_ > 1) ? 3 : 2;
+    static_assert(R0_ * R1_ * R2_ == L_, "radices must multiply to L");
+    static_assert(E % R0_ == 0 && E % R1_ == 0 && E % R2_ == 0, "radix must divide elements per thread");
+    template <int S> static constexpr int LS() { return S == 0 ? L : (S == 1 ? L / R0 : L / (R0 * R1)); }
+    template <int S> static constexpr int R() { return S == 0 ? R0 : (S == 1 ? R1 : R2); }
+};
+
+// In-place position touched by slot e of thread t in stage S.
+template <class C, int S> __device__ __forceinline__ int stage_pos(int t, int e) {
+    constexpr int LS = C::template LS<S>(), R = C::template R<S>();
+    constexpr int M = LS / R, NB = C::E / R;
+    const int u = e % NB, q = e / NB;
+    const int b = t + C::T * u;
+    return (b / M) * LS + (b % M) + M * q;
+}
+
+// How the lines of one workgroup share LDS: address(pos) = off + (pos + pos>>PADSHIFT)*LSTR + xi
+template <int LSTR_, int PADSHIFT_, bool SPLIT_> struct LdsLayout {
+    static constexpr int LSTR = LSTR_, PADSHIFT = PADSHIFT_;
+    static constexpr bool SPLIT = SPLIT_;
+    __device__ __forceinline__ static int addr(int off, int xi, int pos) { return off + (pos + (pos >> PADSHIFT)) * LSTR + xi; }
+    // elements (of 8 or 16 bytes) needed per line
+    static constexpr int line_elems(int L) { return L + (L >> PADSHIFT); }
+    static constexpr int elem_bytes() { return SPLIT ? 8 : 16; }
+};
+
+// COMP: 0 = real parts, 1 = imaginary parts (SPLIT layouts), 2 = whole complex numbers
+template <class C, int S, class LL, int COMP>
+__device__ __forceinline__ void lds_write(const cplx (&v)[C::E], int t, char* smem, int off, int xi) {
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) {
+        const int a = LL::addr(off, xi, stage_pos<C, S>(t, e));
+        if constexpr (COMP == 2) reinterpret_cast<cplx*>(smem)[a] = v[e];
+        else reinterpret_cast<double*>(smem)[a] = (COMP == 0 ? v[e].x : v[e].y);
+    }
+}
+template <class C, int S, class LL, int COMP>
+__device__ __forceinline__ void lds_read(cplx (&v)[C::E], int t, const char* smem, int off, int xi) {
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) {
+        const int a = LL::addr(off, xi, stage_pos<C, S>(t, e));
+        if constexpr (COMP == 2) v[e] = reinterpret_cast<const cplx*>(smem)[a];
+        else if constexpr (COMP == 0) v[e].x = reinterpret_cast<const double*>(smem)[a];
+        else v[e].y = reinterpret_cast<const double*>(smem)[a];
+    }
+}
+
+#ifndef LSFC_FFT_HOST_EMULATION
+// Move every element from its stage-SA owner to its stage-SB owner through LDS.
+template <class C, int SA, int SB, class LL>
+__device__ __forceinline__ void exchange(cplx (&v)[C::E], int t, char* smem, int off, int xi) {
+    if constexpr (LL::SPLIT) {
+        lds_write<C, SA, LL, 0>(v, t, smem, off, xi); LSFC_BARRIER();
+        lds_read<C, SB, LL, 0>(v, t, smem, off, xi);  LSFC_BARRIER();
+        lds_write<C, SA, LL, 1>(v, t, smem, off, xi); LSFC_BARRIER();
+        lds_read<C, SB, LL, 1>(v, t, smem, off, xi);  LSFC_BARRIER();
+    } else {
+        lds_write<C, SA, LL, 2>(v, t, smem, off, xi); LSFC_BARRIER();
+        lds_read<C, SB, LL, 2>(v, t, smem, off, xi);  LSFC_BARRIER();
+    }
+}
+#endif
+
+// One butterfly stage on the register slots.  PRUNE: 0 full; 1 forward with inputs
+// q >= R/2 zero; 2 inverse with only outputs q < R/2 wanted.
+template <class C, int S, int DIR, int PRUNE>
+__device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __restrict__ tw) {
+    constexpr int LS = C::template LS<S>(), R = C::template R<S>();
+    constexpr int M = LS / R, NB = C::E / R;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        cplx a[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) a[q] = v[u + NB * q];
+        cplx w[R];
+        if constexpr (M > 1) {
+            const int r = (t + C::T * u) % M;
+            cplx w1 = tw[r * (C::L / LS)];
+            if constexpr (DIR < 0) w1 = cconj(w1);
+            twiddle_powers<R>(w1, w);
+        }
+        if constexpr (DIR < 0 && M > 1) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) a[q] = cmul(a[q], w[q]);
+        }
+        if constexpr (PRUNE == 1) dft_halfzero<R, DIR>(a);
+        else if constexpr (PRUNE == 2) dft_halfout<R, DIR>(a);
+        else Dft<R, DIR>::run(a);
+        if constexpr (DIR > 0 && M > 1) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) a[q] = cmul(a[q], w[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[u + NB * q] = a[q];
+    }
+}
+
+#ifndef LSFC_FFT_HOST_EMULATION
+// natural (time) order in slots -> storage (digit-reversed frequency) order in slots
+template <class C, class LL, bool PRUNE_IN>
+__device__ __forceinline__ void fft_forward(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
+    stage<C, 0, +1, PRUNE_IN ? 1 : 0>(v, t, tw);
+    exchange<C, 0, 1, LL>(v, t, smem, off, xi);
+    stage<C, 1, +1, 0>(v, t, tw);
+    if constexpr (C::NS == 3) {
+        exchange<C, 1, 2, LL>(v, t, smem, off, xi);
+        stage<C, 2, +1, 0>(v, t, tw);
+    }
+}
+
+// storage order in slots -> natural (time) order in slots, unnormalised
+template <class C, class LL, bool PRUNE_OUT>
+__device__ __forceinline__ void fft_inverse(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
+    if constexpr (C::NS == 3) {
+        stage<C, 2, -1, 0>(v, t, tw);
+        exchange<C, 2, 1, LL>(v, t, smem, off, xi);
+    }
+    stage<C, 1, -1, 0>(v, t, tw);
+    exchange<C, 1, 0, LL>(v, t, smem, off, xi);
+    stage<C, 0, -1, PRUNE_OUT ? 2 : 0>(v, t, tw);
+}
+
+#endif // !LSFC_FFT_HOST_EMULATION
+
+// Host mirror of the slot bookkeeping: frequency index held at storage index s.
+template <class C> inline void perm_table(int* freq_of_storage) {
+    constexpr int RL = (C::NS == 3) ? C::R2 : C::R1;       // radix of the last stage
+    constexpr int NB = C::E / RL;
+    constexpr int M0 = C::L / C::R0;
+    for (int t = 0; t < C::T; ++t)
+        for (int e = 0; e < C::E; ++e) {
+            const int u = e % NB, q = e / NB;
+            const int pos = (t + C::T * u) * RL + q;
+            const int k0 = pos / M0, rem = pos % M0;
+            int k;
+            if (C::NS == 3) { const int k1 = rem / C::R2, k2 = rem % C::R2; k = k0 + C::R0 * (k1 + C::R1 * k2); }
+            else k = k0 + C::R0 * rem;
+            freq_of_storage[t + C::T * e] = k;
+        }
+}
+
+}} // namespace lsfc::fft

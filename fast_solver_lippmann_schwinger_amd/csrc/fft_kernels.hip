@@ -1,0 +1,284 @@
+// Pruned, fused axis passes of the padded-grid convolution (gfx950).
+//
+//   y = alpha*x + beta * crop( IFFT( sym .* FFT( pad( nu .* x ) ) ) )
+//
+// on the reduced grid Lx x Ly x Lz = 2n x 2m x 2l, never touching the zero 7/8 of
+// the padded cube (35 complex + 1 real of HBM traffic per point):
+//
+//   xfwd   x[n][m][l] (*nu)            -> A1[Lx][m][l]            lines contiguous
+//   yfwd   A1                          -> A2[8][l][Ly][Lx/8]      128-B chunks in, 128-B chunks out
+//   zfused A2 (in place) .* sym        -> A2                      fully contiguous 8-line tiles
+//   yinv   A2                          -> A1[Lx][m][l]
+//   xinv   A1, x                       -> y[n][m][l]
+//
+// (2D: xfwd -> zfused along y on the natural A1[Lx][m] -> xinv.)
+// Frequency-side indices are "storage" indices (fft_core.hpp); A2 is tiled so that
+// the eight x'-neighbours of a z-line are interleaved (xi fastest), which makes
+// the largest pass (z: 16 of the 35 complex per point) a pure stream.
+#include "common.hpp"
+#include "fft_configs.hpp"
+#include "pruned.hpp"
+
+namespace lsfc {
+using namespace fft;
+
+static constexpr int XB = 8;           // x' lines per strided workgroup: 8 * 16 B = one 128-B line
+
+template <class C, int LPW, bool SPLIT>
+__global__ __launch_bounds__(C::T * LPW)
+void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __restrict__ out,
+            const cplx* __restrict__ tw, int64_t nlines) {
+    using LL = LdsLayout<1, 3, SPLIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = C::T, E = C::E, n = C::L / 2;
+    const int t = threadIdx.x % T, ll = threadIdx.x / T;
+    const int64_t line = (int64_t)blockIdx.x * LPW + ll;
+    const bool valid = line < nlines;
+    const int64_t lc = valid ? line : nlines - 1;
+    const cplx* xin = x + lc * n;
+    cplx v[E];
+#pragma unroll
+    for (int e = 0; e < E / 2; ++e) v[e] = xin[t + T * e];
+    if (nu) {
+        const double* nin = nu + lc * n;
+#pragma unroll
+        for (int e = 0; e < E / 2; ++e) { const double s = nin[t + T * e]; v[e].x *= s; v[e].y *= s; }
+    }
+#pragma unroll
+    for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
+    fft_forward<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
+    if (valid) {
+        cplx* o = out + line * C::L;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[t + T * e] = v[e];
+    }
+}
+
+template <class C, int LPW, bool SPLIT>
+__global__ __launch_bounds__(C::T * LPW)
+void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alpha, double beta,
+            const cplx* __restrict__ tw, int64_t nlines) {
+    using LL = LdsLayout<1, 3, SPLIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = C::T, E = C::E, n = C::L / 2;
+    const int t = threadIdx.x % T, ll = threadIdx.x / T;
+    const int64_t line = (int64_t)blockIdx.x * LPW + ll;
+    const bool valid = line < nlines;
+    const int64_t lc = valid ? line : nlines - 1;
+    const cplx* i = in + lc * C::L;
+    cplx v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = i[t + T * e];
+    fft_inverse<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
+    if (valid) {
+#pragma unroll
+        for (int e = 0; e < E / 2; ++e) {
+            const int64_t idx = line * n + t + T * e;
+            cplx r = make_double2(beta * v[e].x, beta * v[e].y);
+            if (alpha != 0.0) { const cplx xo = xorig[idx]; r.x = fma(alpha, xo.x, r.x); r.y = fma(alpha, xo.y, r.y); }
+            y[idx] = r;
+        }
+    }
+}
+
+// A1[Lx][m][l] (natural) -> A2[XB][l][Ly][Lx/XB]
+template <class C, int LINES, bool SPLIT>
+__global__ __launch_bounds__(C::T * LINES)
+void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __restrict__ tw, int Lx, int m, int l) {
+    using LL = LdsLayout<LINES, 3, SPLIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = C::T, E = C::E, Ly = C::L;
+    const int xi = threadIdx.x % LINES, t = threadIdx.x / LINES;
+    const int ngrp = Lx / LINES;
+    const int g = blockIdx.x % ngrp, z = blockIdx.x / ngrp;
+    const int xp = g * LINES + xi;                       // x' storage index
+    const cplx* src = a1 + xp + (int64_t)Lx * m * z;
+    cplx v[E];
+#pragma unroll
+    for (int e = 0; e < E / 2; ++e) v[e] = src[(int64_t)Lx * (t + T * e)];
+#pragma unroll
+    for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
+    fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
+    const int xb = xp / XB, xq = xp % XB;
+    cplx* dst = a2 + xq + (int64_t)XB * (z + (int64_t)l * ((int64_t)Ly * xb));
+#pragma unroll
+    for (int e = 0; e < E; ++e) dst[(int64_t)XB * l * (t + T * e)] = v[e];
+}
+
+template <class C, int LINES, bool SPLIT>
+__global__ __launch_bounds__(C::T * LINES)
+void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __restrict__ tw, int Lx, int m, int l) {
+    using LL = LdsLayout<LINES, 3, SPLIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = C::T, E = C::E, Ly = C::L;
+    const int xi = threadIdx.x % LINES, t = threadIdx.x / LINES;
+    const int ngrp = Lx / LINES;
+    const int g = blockIdx.x % ngrp, z = blockIdx.x / ngrp;
+    const int xp = g * LINES + xi;
+    const int xb = xp / XB, xq = xp % XB;
+    const cplx* src = a2 + xq + (int64_t)XB * (z + (int64_t)l * ((int64_t)Ly * xb));
+    cplx v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = src[(int64_t)XB * l * (t + T * e)];
+    fft_inverse<C, LL, true>(v, t, tw, smem, 0, xi);
+    cplx* dst = a1 + xp + (int64_t)Lx * m * z;
+#pragma unroll
+    for (int e = 0; e < E / 2; ++e) dst[(int64_t)Lx * (t + T * e)] = v[e];
+}
+
+// In-place forward -> .* sym -> inverse along one strided axis.
+// Line (g, outer, xi): element j at data[g*dGrp + outer*dOuter + xi + dLine*j],
+// symbol entry for storage index s at sym[g*sGrp + outer*sOuter + xi + sLine*s].
+template <class C, int LINES, bool SPLIT>
+__global__ __launch_bounds__(C::T * LINES)
+void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
+              int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine) {
+    using LL = LdsLayout<LINES, 3, SPLIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = C::T, E = C::E;
+    const int xi = threadIdx.x % LINES, t = threadIdx.x / LINES;
+    const int outer = blockIdx.x % nouter, g = blockIdx.x / nouter;
+    cplx* d = data + g * dGrp + outer * dOuter + xi;
+    const cplx* s = sym + g * sGrp + outer * sOuter + xi;
+    cplx v[E];
+#pragma unroll
+    for (int e = 0; e < E / 2; ++e) v[e] = d[dLine * (t + T * e)];
+#pragma unroll
+    for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
+    fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = cmul(v[e], s[sLine * (t + T * e)]);
+    fft_inverse<C, LL, true>(v, t, tw, smem, 0, xi);
+#pragma unroll
+    for (int e = 0; e < E / 2; ++e) d[dLine * (t + T * e)] = v[e];
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <class K> static void allow_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        LSFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+template <class C> struct Tune {
+    // lines per workgroup: contiguous passes use 256-thread workgroups; strided passes
+    // interleave XB lines unless that would exceed 512 threads.
+    static constexpr int LPW = (256 / C::T) > 0 ? (256 / C::T) : 1;
+    static constexpr int LINES = (C::T * XB <= 512) ? XB : 512 / C::T;
+};
+
+template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, hipStream_t st) {
+    constexpr int LPW = Tune<C>::LPW;
+    using LL = LdsLayout<1, 3, SPLIT>;
+    const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
+    auto k = k_xfwd<C, LPW, SPLIT>;
+    allow_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines);
+}
+template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, hipStream_t st) {
+    constexpr int LPW = Tune<C>::LPW;
+    using LL = LdsLayout<1, 3, SPLIT>;
+    const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
+    auto k = k_xinv<C, LPW, SPLIT>;
+    allow_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines);
+}
+template <class C, bool SPLIT> static void yfwd_t(const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
+    constexpr int LINES = Tune<C>::LINES;
+    using LL = LdsLayout<LINES, 3, SPLIT>;
+    const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
+    auto k = k_yfwd<C, LINES, SPLIT>;
+    allow_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a1, a2, tw, Lx, m, l);
+}
+template <class C, bool SPLIT> static void yinv_t(const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
+    constexpr int LINES = Tune<C>::LINES;
+    using LL = LdsLayout<LINES, 3, SPLIT>;
+    const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
+    auto k = k_yinv<C, LINES, SPLIT>;
+    allow_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l);
+}
+template <class C, bool SPLIT> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+                                                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
+                                                    hipStream_t st) {
+    // dTile/sTile are strides per XB-tile of x'; a workgroup covers LINES of the XB lines of a tile.
+    constexpr int LINES = Tune<C>::LINES;
+    static_assert(XB % LINES == 0, "LINES must divide XB");
+    using LL = LdsLayout<LINES, 3, SPLIT>;
+    const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
+    auto k = k_zfused<C, LINES, SPLIT>;
+    allow_lds(k, lds);
+    if (LINES == XB) {
+        hipLaunchKernelGGL(k, dim3((unsigned)((Lx / XB) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
+                           dTile, dOuter, dLine, sTile, sOuter, sLine);
+    } else {
+        // split each tile into XB/LINES sub-groups: sub-group h starts at xi offset h*LINES
+        // (tile, sub-group) collapse to one group index only when tiles are XB-contiguous in xi (2D natural layout)
+        LSFC_REQUIRE(dTile == XB && sTile == XB, "sub-tile groups need the natural (2D) layout");
+        hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
+                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine);
+    }
+}
+
+static bool env_flag(const char* name, bool dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return v[0] == '1' || v[0] == 'y' || v[0] == 't';
+}
+
+#define LSFC_DISPATCH_L(L, CALL)                                           \
+    switch (L) {                                                           \
+    case 32:   { using C = Cfg32;   CALL; } break;                         \
+    case 64:   { using C = Cfg64;   CALL; } break;                         \
+    case 128:  { using C = Cfg128;  CALL; } break;                         \
+    case 256:  { using C = Cfg256;  CALL; } break;                         \
+    case 512:  { using C = Cfg512;  CALL; } break;                         \
+    case 1024: { using C = Cfg1024; CALL; } break;                         \
+    case 2048: { using C = Cfg2048; CALL; } break;                         \
+    default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); }
+
+bool pruned_length_supported(int64_t L) {
+    return L == 32 || L == 64 || L == 128 || L == 256 || L == 512 || L == 1024 || L == 2048;
+}
+
+void pruned_perm(int L, int* freq_of_storage) {
+    LSFC_DISPATCH_L(L, perm_table<C>(freq_of_storage));
+}
+
+PrunedTuning pruned_default_tuning() {
+    PrunedTuning t;
+    t.split_x = env_flag("LSFC_SPLIT_X", true);
+    t.split_s = env_flag("LSFC_SPLIT_S", true);
+    return t;
+}
+
+void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, hipStream_t st) {
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, st))); }
+    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, st))); }
+    LSFC_HIP(hipGetLastError());
+}
+void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, hipStream_t st) {
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, st))); }
+    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, st))); }
+    LSFC_HIP(hipGetLastError());
+}
+void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
+    if (tn.split_s) { LSFC_DISPATCH_L(L, (yfwd_t<C, true>(a1, a2, tw, Lx, m, l, st))); }
+    else            { LSFC_DISPATCH_L(L, (yfwd_t<C, false>(a1, a2, tw, Lx, m, l, st))); }
+    LSFC_HIP(hipGetLastError());
+}
+void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
+    if (tn.split_s) { LSFC_DISPATCH_L(L, (yinv_t<C, true>(a2, a1, tw, Lx, m, l, st))); }
+    else            { LSFC_DISPATCH_L(L, (yinv_t<C, false>(a2, a1, tw, Lx, m, l, st))); }
+    LSFC_HIP(hipGetLastError());
+}
+void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+                   int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, hipStream_t st) {
+    if (tn.split_s) { LSFC_DISPATCH_L(L, (zfused_t<C, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, st))); }
+    else            { LSFC_DISPATCH_L(L, (zfused_t<C, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, st))); }
+    LSFC_HIP(hipGetLastError());
+}
+
+} // namespace lsfc

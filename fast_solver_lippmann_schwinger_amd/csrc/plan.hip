@@ -1,0 +1,511 @@
+// lsfc C ABI: plan construction, the operator apply, timing helpers (gfx950).
+#include "plan.hpp"
+#include "pointwise.hpp"
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <mutex>
+
+namespace lsfc {
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_last_error[1024] = "";
+void set_last_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_last_error, sizeof g_last_error, fmt, ap); va_end(ap);
+}
+
+// ---------------------------------------------------------------------------
+// rocFFT wrapper
+// ---------------------------------------------------------------------------
+#define LSFC_ROCFFT(expr) do { rocfft_status s_ = (expr); if (s_ != rocfft_status_success) \
+    ::lsfc::fail(LSFC_EHIP, "%s failed with rocfft_status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); } while (0)
+
+void rocfft_global_setup() {
+    static std::once_flag once;
+    std::call_once(once, [] { rocfft_setup(); });
+}
+
+RocFft::~RocFft() {
+    if (info) rocfft_execution_info_destroy(info);
+    if (plan) rocfft_plan_destroy(plan);
+}
+void RocFft::finish_create() {
+    size_t wsz = 0;
+    LSFC_ROCFFT(rocfft_plan_get_work_buffer_size(plan, &wsz));
+    LSFC_ROCFFT(rocfft_execution_info_create(&info));
+    if (wsz) { work.alloc(wsz); LSFC_ROCFFT(rocfft_execution_info_set_work_buffer(info, work.p, wsz)); }
+}
+void RocFft::create(int ndim, const size_t* lengths, bool forward, size_t batch) {
+    rocfft_global_setup();
+    // drop unit dimensions
+    size_t len[3]; int nd = 0;
+    for (int d = 0; d < ndim; ++d) if (lengths[d] > 1) len[nd++] = lengths[d];
+    if (nd == 0) { len[0] = 1; nd = 1; }
+    LSFC_ROCFFT(rocfft_plan_create(&plan, rocfft_placement_inplace,
+                                   forward ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
+                                   rocfft_precision_double, nd, len, batch, nullptr));
+    finish_create();
+}
+void RocFft::create_strided_1d(size_t length, size_t stride, size_t dist, size_t batch, bool forward) {
+    rocfft_global_setup();
+    rocfft_plan_description desc = nullptr;
+    LSFC_ROCFFT(rocfft_plan_description_create(&desc));
+    const size_t strides[1] = { stride };
+    rocfft_status s = rocfft_plan_description_set_data_layout(desc, rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved,
+                                                              nullptr, nullptr, 1, strides, dist, 1, strides, dist);
+    if (s == rocfft_status_success)
+        s = rocfft_plan_create(&plan, rocfft_placement_inplace,
+                               forward ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
+                               rocfft_precision_double, 1, &length, batch, desc);
+    rocfft_plan_description_destroy(desc);
+    LSFC_ROCFFT(s);
+    finish_create();
+}
+void RocFft::exec(void* buf, hipStream_t stream) {
+    LSFC_ROCFFT(rocfft_execution_info_set_stream(info, stream));
+    void* in[1] = { buf };
+    LSFC_ROCFFT(rocfft_execute(plan, in, nullptr, info));
+}
+
+// ---------------------------------------------------------------------------
+// plan construction helpers
+// ---------------------------------------------------------------------------
+static void select_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) fail(LSFC_ENODEV, "no HIP device available (%s): the lsfc operator has no CPU fallback",
+                                            e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    LSFC_REQUIRE(device >= 0 && device < count, "device %d out of range (have %d)", device, count);
+    LSFC_HIP(hipSetDevice(device));
+}
+
+void plan_common_init(lsfc_plan* p, int ndim, int64_t n, int64_t m, int64_t l, const double* nu_host, double omega,
+                      int quad_rule, unsigned flags, int device) {
+    LSFC_REQUIRE(n >= 1 && m >= 1 && l >= 1 && n <= 8192 && m <= 8192 && l <= 8192, "grid size out of range");
+    LSFC_REQUIRE(quad_rule == LSFC_QUAD_TRAPEZOIDAL || quad_rule == LSFC_QUAD_GREENGARD_VICO,
+                 "unknown quadRule %d (the reference leaves B undefined, src/FastConvolution.jl:106)", quad_rule);
+    LSFC_REQUIRE(nu_host != nullptr, "nu is NULL");
+    select_device(device);
+    p->device = device; p->ndim = ndim;
+    p->dims[0] = (int)n; p->dims[1] = (int)m; p->dims[2] = (int)l;
+    p->N = n * m * l; p->omega = omega; p->quad_rule = quad_rule; p->flags = flags;
+    p->nu.alloc((size_t)p->N);
+    LSFC_HIP(hipMemcpy(p->nu.p, nu_host, p->N * sizeof(double), hipMemcpyHostToDevice));
+    p->tuning = pruned_default_tuning();
+}
+
+static void make_twiddles(lsfc_plan* p, int axis, int L) {
+    std::vector<cplx> tw((size_t)L);
+    for (int j = 0; j < L; ++j) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)L;
+        tw[j] = make_double2((double)cosl(a), (double)sinl(a));
+    }
+    p->tw[axis].alloc((size_t)L);
+    LSFC_HIP(hipMemcpy(p->tw[axis].p, tw.data(), (size_t)L * sizeof(cplx), hipMemcpyHostToDevice));
+}
+
+static bool pruned_eligible(const lsfc_plan* p) {
+    if (p->flags & (LSFC_FLAG_FORCE_ROCFFT | LSFC_FLAG_LITERAL_PAD)) return false;
+    for (int d = 0; d < p->ndim; ++d) if (!pruned_length_supported(2 * (int64_t)p->dims[d])) return false;
+    return true;
+}
+
+static void setup_rocfft_pipeline(lsfc_plan* p) {
+    const size_t len[3] = { (size_t)p->pads[0], (size_t)p->pads[1], (size_t)p->pads[2] };
+    p->fwd.reset(new RocFft()); p->fwd->create(3, len, true);
+    p->inv.reset(new RocFft()); p->inv->create(3, len, false);
+    p->W.alloc(len[0] * len[1] * len[2]);
+}
+
+void plan_finish_literal(lsfc_plan* p, const cplx* Gd, bool centred) {
+    // working grid == the caller's padded grid; symbol pre-shifted and pre-scaled once
+    const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
+    p->sym.alloc((size_t)total);
+    int shift[3];
+    for (int d = 0; d < 3; ++d) shift[d] = centred ? p->pads[d] / 2 : 0;
+    pw_roll_scale(Gd, p->sym.p, p->pads, shift, 1.0 / (double)total, p->stream);
+    p->pipeline = lsfc_plan::ROCFFT_LITERAL;
+    setup_rocfft_pipeline(p);
+    LSFC_HIP(hipStreamSynchronize(p->stream));
+}
+
+void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
+    for (int d = 0; d < 3; ++d) { p->pads[d] = (d < p->ndim) ? 2 * p->dims[d] : 1; p->crop[d] = 0; }
+    const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
+    const double scale = 1.0 / (double)total;
+    if (pruned_eligible(p)) {
+        std::vector<int> perm[3];
+        DevBuf<int> dperm[3];
+        for (int d = 0; d < p->ndim; ++d) {
+            perm[d].resize((size_t)p->pads[d]);
+            pruned_perm(p->pads[d], perm[d].data());
+            dperm[d].alloc(perm[d].size());
+            LSFC_HIP(hipMemcpy(dperm[d].p, perm[d].data(), perm[d].size() * sizeof(int), hipMemcpyHostToDevice));
+            make_twiddles(p, d, p->pads[d]);
+        }
+        p->sym.alloc((size_t)total);
+        pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, scale, p->stream);
+        LSFC_HIP(hipStreamSynchronize(p->stream));
+        G2.release();
+        p->A1.alloc((size_t)p->pads[0] * p->dims[1] * p->dims[2]);
+        if (p->ndim == 3) p->A2.alloc((size_t)p->pads[0] * p->pads[1] * p->dims[2]);
+        p->pipeline = lsfc_plan::PRUNED;
+    } else {
+        pw_scale(G2.p, scale, total, p->stream);
+        LSFC_HIP(hipStreamSynchronize(p->stream));
+        p->sym = std::move(G2);
+        p->pipeline = lsfc_plan::ROCFFT_REDUCED;
+        setup_rocfft_pipeline(p);
+    }
+}
+
+void plan_finish_reduce(lsfc_plan* p, DevBuf<cplx>& Gd, const int lit[3], bool centred) {
+    // T = ifft(ifftshift(G)) on the literal grid, keep offsets -n..n-1 per axis, G2 = fft(T2)
+    for (int d = 0; d < p->ndim; ++d)
+        LSFC_REQUIRE(lit[d] >= 2 * p->dims[d], "padded size %d along axis %d is smaller than 2n=%d", lit[d], d, 2 * p->dims[d]);
+    const int64_t ltotal = (int64_t)lit[0] * lit[1] * lit[2];
+    int q[3]; for (int d = 0; d < 3; ++d) q[d] = (d < p->ndim) ? 2 * p->dims[d] : 1;
+    const int64_t qtotal = (int64_t)q[0] * q[1] * q[2];
+    {
+        DevBuf<cplx> tmp; tmp.alloc((size_t)ltotal);
+        int shift[3]; for (int d = 0; d < 3; ++d) shift[d] = centred ? lit[d] / 2 : 0;
+        pw_roll_scale(Gd.p, tmp.p, lit, shift, 1.0, p->stream);
+        LSFC_HIP(hipStreamSynchronize(p->stream));
+        Gd.release();
+        const size_t len[3] = { (size_t)lit[0], (size_t)lit[1], (size_t)lit[2] };
+        RocFft inv; inv.create(3, len, false);
+        inv.exec(tmp.p, p->stream);
+        Gd.alloc((size_t)qtotal);
+        pw_wrap_crop(tmp.p, Gd.p, lit, q, 1.0 / (double)ltotal, p->stream);
+        LSFC_HIP(hipStreamSynchronize(p->stream));
+    }
+    {
+        const size_t len[3] = { (size_t)q[0], (size_t)q[1], (size_t)q[2] };
+        RocFft fwd; fwd.create(3, len, true);
+        fwd.exec(Gd.p, p->stream);
+        LSFC_HIP(hipStreamSynchronize(p->stream));
+    }
+    plan_finish_from_reduced(p, Gd);
+}
+
+// ---------------------------------------------------------------------------
+// the apply
+// ---------------------------------------------------------------------------
+void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta) {
+    const double* nu = use_nu ? p->nu.p : nullptr;
+    hipStream_t st = p->stream;
+    if (p->pipeline == lsfc_plan::PRUNED) {
+        const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
+        const int m = p->dims[1], l = p->dims[2];
+        const int64_t nlines = (int64_t)m * l;
+        pruned_xfwd(Lx, p->tuning, x, nu, p->A1.p, p->tw[0].p, nlines, st);
+        if (p->ndim == 3) {
+            pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, st);
+            pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
+                          (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * Ly, (int64_t)8 * Lz, 8, st);
+            pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, st);
+        } else {
+            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, Lx, 8, 0, Lx, st);
+        }
+        pruned_xinv(Lx, p->tuning, p->A1.p, x, y, alpha, beta, p->tw[0].p, nlines, st);
+    } else {
+        const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
+        pw_embed(x, nu, p->W.p, p->dims, p->pads, st);
+        p->fwd->exec(p->W.p, st);
+        pw_mul_inplace(p->W.p, p->sym.p, total, st);
+        p->inv->exec(p->W.p, st);
+        pw_crop_axpy(p->W.p, x, y, alpha, beta, p->dims, p->pads, p->crop, st);
+    }
+}
+
+static void ensure_staging(lsfc_plan* p, int64_t count) {
+    if (p->xs.n < (size_t)count) { p->xs.alloc((size_t)count); p->ys.alloc((size_t)count); }
+}
+
+static void convolve_any(lsfc_plan* p, const double* x, double* y, int64_t nrhs, bool use_nu, double alpha, double beta, int memspace) {
+    LSFC_REQUIRE(p && x && y, "NULL argument");
+    LSFC_REQUIRE(nrhs >= 1, "nrhs must be >= 1");
+    LSFC_HIP(hipSetDevice(p->device));
+    if (memspace == LSFC_MEM_DEVICE) {
+        for (int64_t j = 0; j < nrhs; ++j)
+            plan_convolve_dev(p, (const cplx*)x + j * p->N, (cplx*)y + j * p->N, use_nu, alpha, beta);
+        return;
+    }
+    LSFC_REQUIRE(memspace == LSFC_MEM_HOST, "unknown memspace %d", memspace);
+    ensure_staging(p, p->N);
+    for (int64_t j = 0; j < nrhs; ++j) {
+        LSFC_HIP(hipMemcpyAsync(p->xs.p, (const cplx*)x + j * p->N, p->N * sizeof(cplx), hipMemcpyHostToDevice, p->stream));
+        plan_convolve_dev(p, p->xs.p, p->ys.p, use_nu, alpha, beta);
+        LSFC_HIP(hipMemcpyAsync((cplx*)y + j * p->N, p->ys.p, p->N * sizeof(cplx), hipMemcpyDeviceToHost, p->stream));
+        LSFC_HIP(hipStreamSynchronize(p->stream));
+    }
+}
+
+} // namespace lsfc
+
+using namespace lsfc;
+
+lsfc_plan::lsfc_plan() {}
+lsfc_plan::~lsfc_plan() {}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* lsfc_last_error(void) { return g_last_error; }
+const char* lsfc_version(void) { return "lsfc 0.1 (gfx950, rocFFT + hand-written pruned FFT passes)"; }
+
+static int create_from_literal(lsfc_plan** out, int ndim, int64_t n, int64_t m, int64_t l, int64_t ne, int64_t me, int64_t le,
+                               const double* nu, const double* gfft, double omega, int quad_rule, unsigned flags, int device) {
+    return guarded([&] {
+        LSFC_REQUIRE(out && gfft, "NULL argument");
+        *out = nullptr;
+        std::unique_ptr<lsfc_plan> p(new lsfc_plan());
+        plan_common_init(p.get(), ndim, n, m, l, nu, omega, quad_rule, flags, device);
+        LSFC_REQUIRE(ne >= 1 && me >= 1 && le >= 1 && ne <= 16384 && me <= 16384 && le <= 16384, "padded size out of range");
+        const int lit[3] = { (int)ne, (int)me, (int)le };
+        const int64_t ltotal = ne * me * le;
+        DevBuf<cplx> Gd; Gd.alloc((size_t)ltotal);
+        LSFC_HIP(hipMemcpy(Gd.p, gfft, (size_t)ltotal * sizeof(cplx), hipMemcpyHostToDevice));
+        if (quad_rule == LSFC_QUAD_TRAPEZOIDAL) {
+            // plain FFT-order symbol on the (2n-1) grid, crop window [n-1, 2n-2] (src/FastConvolution.jl:70-82)
+            for (int d = 0; d < ndim; ++d)
+                LSFC_REQUIRE(lit[d] >= 2 * p->dims[d] - 1, "trapezoidal: padded size %d < 2n-1 along axis %d", lit[d], d);
+            for (int d = 0; d < 3; ++d) { p->pads[d] = lit[d]; p->crop[d] = (d < ndim) ? p->dims[d] - 1 : 0; }
+            plan_finish_literal(p.get(), Gd.p, false);
+        } else if (flags & LSFC_FLAG_LITERAL_PAD) {
+            for (int d = 0; d < ndim; ++d) LSFC_REQUIRE(lit[d] >= p->dims[d], "padded size smaller than the grid");
+            for (int d = 0; d < 3; ++d) { p->pads[d] = lit[d]; p->crop[d] = 0; }
+            plan_finish_literal(p.get(), Gd.p, true);
+        } else {
+            plan_finish_reduce(p.get(), Gd, lit, true);
+        }
+        *out = p.release();
+    });
+}
+
+int lsfc_plan_create_2d(lsfc_plan** out, int64_t n, int64_t m, int64_t ne, int64_t me, const double* nu, const double* gfft,
+                        double omega, int quad_rule, unsigned flags, int device) {
+    return create_from_literal(out, 2, n, m, 1, ne, me, 1, nu, gfft, omega, quad_rule, flags, device);
+}
+int lsfc_plan_create_3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, int64_t ne, int64_t me, int64_t le, const double* nu,
+                        const double* gfft, double omega, int quad_rule, unsigned flags, int device) {
+    return create_from_literal(out, 3, n, m, l, ne, me, le, nu, gfft, omega, quad_rule, flags, device);
+}
+
+int lsfc_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega, const double* nu,
+                          unsigned flags, int device) {
+    return guarded([&] {
+        LSFC_REQUIRE(out, "NULL argument"); *out = nullptr;
+        LSFC_REQUIRE(n % 2 == 0 && m % 2 == 0 && l % 2 == 0, "buildFastConvolution3D: even n only (the reference's odd branch is broken)");
+        LSFC_REQUIRE(box > 0, "box must be positive");
+        std::unique_ptr<lsfc_plan> p(new lsfc_plan());
+        plan_common_init(p.get(), 3, n, m, l, nu, omega, LSFC_QUAD_GREENGARD_VICO, flags & ~LSFC_FLAG_LITERAL_PAD, device);
+        DevBuf<cplx> G2;
+        symbol_gv3d_reduced(p.get(), box, G2);
+        plan_finish_from_reduced(p.get(), G2);
+        *out = p.release();
+    });
+}
+
+int lsfc_plan_create_gv2d(lsfc_plan** out, int64_t n, int64_t m, double box, double omega, const double* nu, unsigned flags, int device) {
+    return guarded([&] {
+        LSFC_REQUIRE(out, "NULL argument"); *out = nullptr;
+        LSFC_REQUIRE(box > 0, "box must be positive");
+        std::unique_ptr<lsfc_plan> p(new lsfc_plan());
+        plan_common_init(p.get(), 2, n, m, 1, nu, omega, LSFC_QUAD_GREENGARD_VICO, flags, device);
+        DevBuf<cplx> G; int lit[3];
+        symbol_gv2d_literal(p.get(), box, G, lit);
+        if (flags & LSFC_FLAG_LITERAL_PAD) {
+            for (int d = 0; d < 3; ++d) { p->pads[d] = lit[d]; p->crop[d] = 0; }
+            plan_finish_literal(p.get(), G.p, true);
+        } else plan_finish_reduce(p.get(), G, lit, true);
+        *out = p.release();
+    });
+}
+
+int lsfc_plan_create_trap2d(lsfc_plan** out, int64_t n, int64_t m, double x0, double y0, double h, double omega,
+                            double d0_re, double d0_im, const double* nu, unsigned flags, int device) {
+    return guarded([&] {
+        LSFC_REQUIRE(out, "NULL argument"); *out = nullptr;
+        LSFC_REQUIRE(n % 2 == 1 && m % 2 == 1, "so far only works for n odd (src/FastConvolution.jl:455)");
+        std::unique_ptr<lsfc_plan> p(new lsfc_plan());
+        plan_common_init(p.get(), 2, n, m, 1, nu, omega, LSFC_QUAD_TRAPEZOIDAL, flags, device);
+        DevBuf<cplx> G;
+        symbol_trap2d_literal(p.get(), x0, y0, h, make_double2(d0_re, d0_im), G);
+        p->pads[0] = 2 * (int)n - 1; p->pads[1] = 2 * (int)m - 1; p->pads[2] = 1;
+        p->crop[0] = (int)n - 1; p->crop[1] = (int)m - 1; p->crop[2] = 0;
+        plan_finish_literal(p.get(), G.p, false);
+        *out = p.release();
+    });
+}
+
+int lsfc_plan_destroy(lsfc_plan* plan) {
+    return guarded([&] { if (plan) { (void)hipSetDevice(plan->device); (void)hipStreamSynchronize(plan->stream); delete plan; } });
+}
+
+int64_t lsfc_plan_size(const lsfc_plan* plan) { return plan ? plan->N : -1; }
+
+int lsfc_plan_dims(const lsfc_plan* plan, int64_t dims[3], int64_t pads[3]) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan, "NULL plan");
+        for (int d = 0; d < 3; ++d) { if (dims) dims[d] = plan->dims[d]; if (pads) pads[d] = plan->pads[d]; }
+    });
+}
+
+const char* lsfc_plan_pipeline(const lsfc_plan* plan) {
+    if (!plan) return "";
+    switch (plan->pipeline) {
+    case lsfc_plan::PRUNED: return "pruned-hip";
+    case lsfc_plan::ROCFFT_REDUCED: return "rocfft-reduced";
+    default: return "rocfft-literal";
+    }
+}
+
+int lsfc_plan_set_nu(lsfc_plan* plan, const double* nu, int memspace) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan && nu, "NULL argument");
+        LSFC_HIP(hipSetDevice(plan->device));
+        LSFC_HIP(hipMemcpyAsync(plan->nu.p, nu, plan->N * sizeof(double),
+                                memspace == LSFC_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, plan->stream));
+        LSFC_HIP(hipStreamSynchronize(plan->stream));
+    });
+}
+
+int lsfc_plan_get_symbol(const lsfc_plan* plan, double* out, int64_t capacity_complex, int64_t* count) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan && count, "NULL argument");
+        *count = (int64_t)plan->sym.n;
+        if (out) {
+            LSFC_REQUIRE(capacity_complex >= (int64_t)plan->sym.n, "buffer too small");
+            LSFC_HIP(hipMemcpy(out, plan->sym.p, plan->sym.bytes(), hipMemcpyDeviceToHost));
+        }
+    });
+}
+
+int lsfc_apply(lsfc_plan* plan, const double* x, double* y, int memspace) {
+    return guarded([&] { LSFC_REQUIRE(plan, "NULL plan"); convolve_any(plan, x, y, 1, true, 1.0, plan->omega * plan->omega, memspace); });
+}
+int lsfc_convolve(lsfc_plan* plan, const double* x, double* y, int apply_nu, int memspace) {
+    return guarded([&] { convolve_any(plan, x, y, 1, apply_nu != 0, 0.0, 1.0, memspace); });
+}
+int lsfc_apply_batch(lsfc_plan* plan, const double* x, double* y, int64_t nrhs, int mode, int memspace) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan, "NULL plan");
+        LSFC_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (apply), 1 (convolve) or 2 (convolve with nu)");
+        if (mode == 0) convolve_any(plan, x, y, nrhs, true, 1.0, plan->omega * plan->omega, memspace);
+        else convolve_any(plan, x, y, nrhs, mode == 2, 0.0, 1.0, memspace);
+    });
+}
+
+int lsfc_gmres(lsfc_plan* plan, double* x, const double* b, const lsfc_gmres_opts* opts, double* resnorm, int64_t resnorm_cap,
+               lsfc_gmres_result* result, int memspace) {
+    int conv_code = LSFC_OK;
+    int rc = guarded([&] {
+        LSFC_REQUIRE(plan && x && b, "NULL argument");
+        LSFC_HIP(hipSetDevice(plan->device));
+        lsfc_gmres_result local; lsfc_gmres_result* res = result ? result : &local;
+        if (memspace == LSFC_MEM_DEVICE) {
+            gmres_run(plan, (cplx*)x, (const cplx*)b, opts, resnorm, resnorm_cap, res);
+        } else {
+            LSFC_REQUIRE(memspace == LSFC_MEM_HOST, "unknown memspace %d", memspace);
+            ensure_staging(plan, plan->N);
+            LSFC_HIP(hipMemcpy(plan->xs.p, x, plan->N * sizeof(cplx), hipMemcpyHostToDevice));
+            LSFC_HIP(hipMemcpy(plan->ys.p, b, plan->N * sizeof(cplx), hipMemcpyHostToDevice));
+            gmres_run(plan, plan->xs.p, plan->ys.p, opts, resnorm, resnorm_cap, res);
+            LSFC_HIP(hipMemcpy(x, plan->xs.p, plan->N * sizeof(cplx), hipMemcpyDeviceToHost));
+        }
+        if (!res->converged) conv_code = LSFC_ENOTCONV;
+    });
+    if (rc == LSFC_OK && conv_code != LSFC_OK) { set_last_error("gmres: maxiter reached without convergence"); return conv_code; }
+    return rc;
+}
+
+int lsfc_plan_set_stream(lsfc_plan* plan, void* hip_stream) {
+    return guarded([&] { LSFC_REQUIRE(plan, "NULL plan"); plan->stream = (hipStream_t)hip_stream; });
+}
+int lsfc_plan_synchronize(lsfc_plan* plan) {
+    return guarded([&] { LSFC_REQUIRE(plan, "NULL plan"); LSFC_HIP(hipSetDevice(plan->device)); LSFC_HIP(hipStreamSynchronize(plan->stream)); });
+}
+
+int lsfc_time_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int reps, double* ms_total) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan && x_dev && y_dev && ms_total && reps >= 1, "bad argument");
+        LSFC_HIP(hipSetDevice(plan->device));
+        hipEvent_t e0, e1;
+        LSFC_HIP(hipEventCreate(&e0)); LSFC_HIP(hipEventCreate(&e1));
+        LSFC_HIP(hipEventRecord(e0, plan->stream));
+        for (int r = 0; r < reps; ++r) plan_apply_dev(plan, (const cplx*)x_dev, (cplx*)y_dev);
+        LSFC_HIP(hipEventRecord(e1, plan->stream));
+        LSFC_HIP(hipEventSynchronize(e1));
+        float ms = 0; LSFC_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *ms_total = ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    });
+}
+
+int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int reps, int max_stages, const char** names,
+                       double* ms, double* bytes, int* nstages) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan && x_dev && y_dev && names && ms && bytes && nstages && reps >= 1, "bad argument");
+        LSFC_HIP(hipSetDevice(plan->device));
+        lsfc_plan* p = plan;
+        const cplx* x = (const cplx*)x_dev; cplx* y = (cplx*)y_dev;
+        hipStream_t st = p->stream;
+        const double N = (double)p->N, C = 16.0;
+        struct Stage { const char* name; double bytes; std::function<void()> run; };
+        std::vector<Stage> stages;
+        const double om2 = p->omega * p->omega;
+        if (p->pipeline == lsfc_plan::PRUNED) {
+            const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
+            const int m = p->dims[1], l = p->dims[2];
+            const int64_t nlines = (int64_t)m * l;
+            stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, [=] { pruned_xfwd(Lx, p->tuning, x, p->nu.p, p->A1.p, p->tw[0].p, nlines, st); }});
+            if (p->ndim == 3) {
+                stages.push_back({"yfwd", (2 + 4) * N * C, [=] { pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, st); }});
+                stages.push_back({"zfused", (4 + 8 + 4) * N * C, [=] { pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
+                                  (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * Ly, (int64_t)8 * Lz, 8, st); }});
+                stages.push_back({"yinv", (4 + 2) * N * C, [=] { pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, st); }});
+            } else {
+                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, Lx, 8, 0, Lx, st); }});
+            }
+            stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, st); }});
+        } else {
+            const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
+            const double P = (double)total;
+            stages.push_back({"embed", N * (C + 8) + P * C, [=] { pw_embed(x, p->nu.p, p->W.p, p->dims, p->pads, st); }});
+            stages.push_back({"rocfft_fwd", 2 * P * C, [=] { p->fwd->exec(p->W.p, st); }});
+            stages.push_back({"symbol_mul", 3 * P * C, [=] { pw_mul_inplace(p->W.p, p->sym.p, total, st); }});
+            stages.push_back({"rocfft_inv", 2 * P * C, [=] { p->inv->exec(p->W.p, st); }});
+            stages.push_back({"crop_axpy", 3 * N * C, [=] { pw_crop_axpy(p->W.p, x, y, 1.0, om2, p->dims, p->pads, p->crop, st); }});
+        }
+        LSFC_REQUIRE((int)stages.size() <= max_stages, "max_stages too small (need %d)", (int)stages.size());
+        *nstages = (int)stages.size();
+        std::vector<hipEvent_t> ev(stages.size() + 1);
+        for (auto& e : ev) LSFC_HIP(hipEventCreate(&e));
+        for (size_t i = 0; i < stages.size(); ++i) { names[i] = stages[i].name; bytes[i] = stages[i].bytes; ms[i] = 0.0; }
+        for (int r = 0; r < reps; ++r) {
+            LSFC_HIP(hipEventRecord(ev[0], st));
+            for (size_t i = 0; i < stages.size(); ++i) { stages[i].run(); LSFC_HIP(hipEventRecord(ev[i + 1], st)); }
+            LSFC_HIP(hipEventSynchronize(ev[stages.size()]));
+            for (size_t i = 0; i < stages.size(); ++i) { float t = 0; LSFC_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1])); ms[i] += t; }
+        }
+        for (size_t i = 0; i < stages.size(); ++i) ms[i] /= reps;
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    });
+}
+
+int lsfc_device_count(int* count) {
+    return guarded([&] { LSFC_REQUIRE(count, "NULL argument"); int c = 0; hipError_t e = hipGetDeviceCount(&c); *count = (e == hipSuccess) ? c : 0; });
+}
+int lsfc_malloc(void** dptr, size_t bytes, int device) {
+    return guarded([&] { LSFC_REQUIRE(dptr, "NULL argument"); select_device(device); LSFC_HIP(hipMalloc(dptr, bytes)); });
+}
+int lsfc_free(void* dptr) { return guarded([&] { if (dptr) LSFC_HIP(hipFree(dptr)); }); }
+int lsfc_memcpy_h2d(void* dst, const void* src, size_t bytes) { return guarded([&] { LSFC_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }); }
+int lsfc_memcpy_d2h(void* dst, const void* src, size_t bytes) { return guarded([&] { LSFC_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); }); }
+
+} // extern "C"

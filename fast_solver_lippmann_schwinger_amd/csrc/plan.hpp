@@ -1,0 +1,117 @@
+// The plan object behind the lsfc C ABI.
+#pragma once
+#include "common.hpp"
+#include "pruned.hpp"
+#include <rocfft/rocfft.h>
+#include <memory>
+#include <vector>
+
+namespace lsfc {
+
+// Thin RAII wrapper of one in-place complex-double rocFFT transform.
+struct RocFft {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    DevBuf<char> work;
+    RocFft() = default;
+    RocFft(const RocFft&) = delete; RocFft& operator=(const RocFft&) = delete;
+    ~RocFft();
+    // dense ndim-dimensional transform (lengths fastest first), `batch` contiguous copies
+    void create(int ndim, const size_t* lengths, bool forward, size_t batch = 1);
+    // 1D transforms of `length` with element stride `stride`, `batch` lines `dist` apart
+    void create_strided_1d(size_t length, size_t stride, size_t dist, size_t batch, bool forward);
+    void exec(void* buf, hipStream_t stream);
+private:
+    void finish_create();
+};
+
+void rocfft_global_setup();
+
+// GMRES workspace, allocated lazily and kept across solves (gmres.hip)
+struct GmresWorkspace {
+    int restart = 0;
+    DevBuf<cplx> V;          // (restart + 1) basis vectors of length N, column after column
+    DevBuf<cplx> hdev;       // Hessenberg column of the current step (restart + 2 entries)
+    DevBuf<cplx> ydev;       // least-squares solution at restart
+    DevBuf<cplx> partial;    // reduction scratch
+    DevBuf<cplx> ax;         // A*x workspace
+    cplx* hpin = nullptr;    // pinned host mirror of hdev
+    cplx* vpin = nullptr;    // pinned host vector for the preconditioner callback
+    ~GmresWorkspace();
+};
+
+// slab-distributed state (dist.hip)
+struct DistState {
+    int rank = 0, nranks = 1;
+    void* comm = nullptr;    // ncclComm_t
+    int lz = 0;              // local z planes
+    int xw = 0;              // local width in x' after the transpose (Lx / nranks)
+    DevBuf<cplx> sendbuf, recvbuf;
+    ~DistState();
+};
+
+} // namespace lsfc
+
+struct lsfc_plan {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int ndim = 3;
+    int dims[3] = {1, 1, 1};        // n, m, l
+    int pads[3] = {1, 1, 1};        // padded working grid
+    int crop[3] = {0, 0, 0};        // crop window offset in the padded grid
+    int64_t N = 0;
+    double omega = 0.0;
+    int quad_rule = LSFC_QUAD_GREENGARD_VICO;
+    unsigned flags = 0;
+    enum Pipeline { PRUNED = 0, ROCFFT_REDUCED = 1, ROCFFT_LITERAL = 2 } pipeline = PRUNED;
+
+    lsfc::DevBuf<double> nu;
+    lsfc::DevBuf<lsfc::cplx> sym;        // pruned: storage-order tiled layout incl. 1/|pads|; rocFFT: FFT order incl. 1/|pads|
+
+    // pruned pipeline
+    lsfc::PrunedTuning tuning;
+    lsfc::DevBuf<lsfc::cplx> tw[3];
+    lsfc::DevBuf<lsfc::cplx> A1, A2;
+
+    // rocFFT pipelines
+    std::unique_ptr<lsfc::RocFft> fwd, inv;
+    lsfc::DevBuf<lsfc::cplx> W;
+
+    // staging for host-resident vectors
+    lsfc::DevBuf<lsfc::cplx> xs, ys;
+
+    std::unique_ptr<lsfc::GmresWorkspace> gmres;
+    std::unique_ptr<lsfc::DistState> dist;
+
+    lsfc_plan();
+    ~lsfc_plan();
+};
+
+namespace lsfc {
+
+// y = alpha*x + beta*conv((use_nu ? nu : 1) .* x); device pointers, stream-ordered.
+void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta);
+// the operator M = I + omega^2 G nu
+inline void plan_apply_dev(lsfc_plan* p, const cplx* x, cplx* y) { plan_convolve_dev(p, x, y, true, 1.0, p->omega * p->omega); }
+
+// Finish a plan from a natural-layout symbol already on the device.
+//   literal: Gd has p->pads entries; centred => ifftshift is folded in.  Takes ownership of nothing.
+void plan_finish_literal(lsfc_plan* p, const cplx* Gd, bool centred);
+//   reduce a (pe,me,le) symbol (centred or FFT order) to the (2n,2m,2l) grid and pick the pipeline
+void plan_finish_reduce(lsfc_plan* p, DevBuf<cplx>& Gd, const int lit[3], bool centred);
+//   G2 natural FFT order on the (2n,2m,2l) grid, unscaled
+void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2);
+
+void plan_common_init(lsfc_plan* p, int ndim, int64_t n, int64_t m, int64_t l, const double* nu_host, double omega,
+                      int quad_rule, unsigned flags, int device);
+
+// symbol generators (symbol.hip)
+void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2);                  // -> (2n,2m,2l) FFT order, unscaled
+void symbol_gv2d_literal(lsfc_plan* p, double box, DevBuf<cplx>& G, int lit[3]);       // -> (4n,4m) centred
+void symbol_trap2d_literal(lsfc_plan* p, double x0, double y0, double h, cplx d0, DevBuf<cplx>& G); // -> fft(Ge), (2n-1,2m-1)
+
+// GMRES (gmres.hip)
+void gmres_run(lsfc_plan* p, cplx* x_dev, const cplx* b_dev, const lsfc_gmres_opts* opts, double* resnorm, int64_t cap,
+               lsfc_gmres_result* res);
+
+} // namespace lsfc

@@ -1,0 +1,302 @@
+// Element-wise and reduction kernels (gfx950): padded embed / crop for the rocFFT
+// pipelines, symbol preparation at plan creation, and the BLAS-1 pieces of GMRES.
+// All are HBM-bound: 16 B per lane accesses, grid-stride loops, wave64 shuffle
+// reductions with a fixed-order second stage (bitwise reproducible, no float atomics).
+#include "common.hpp"
+#include "pointwise.hpp"
+
+namespace lsfc {
+
+static inline unsigned grid_for(int64_t count, int block = 256, int cap = 256 * 16) {
+    int64_t g = (count + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// ---- rocFFT pipelines: embed and crop ---------------------------------------
+
+// W[p0][p1][p2] (x fastest) = (i<n && j<m && k<l) ? (nu?nu:1)*x : 0
+__global__ void k_embed(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __restrict__ W,
+                        int n, int m, int l, int p0, int p1, int p2) {
+    const int64_t total = (int64_t)p0 * p1 * p2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % p0); const int64_t r = idx / p0; const int j = (int)(r % p1); const int k = (int)(r / p1);
+        cplx v = make_double2(0.0, 0.0);
+        if (i < n && j < m && k < l) {
+            const int64_t s = i + (int64_t)n * (j + (int64_t)m * k);
+            v = x[s];
+            if (nu) { const double c = nu[s]; v.x *= c; v.y *= c; }
+        }
+        W[idx] = v;
+    }
+}
+
+__global__ void k_mul_inplace(cplx* __restrict__ W, const cplx* __restrict__ S, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const cplx a = W[idx], b = S[idx];
+        W[idx] = make_double2(fma(-a.y, b.y, a.x * b.x), fma(a.x, b.y, a.y * b.x));
+    }
+}
+
+// y = alpha*x + beta*W[o0+i][o1+j][o2+k]
+__global__ void k_crop_axpy(const cplx* __restrict__ W, const cplx* x, cplx* y, double alpha, double beta,
+                            int n, int m, int l, int p0, int p1, int o0, int o1, int o2) {
+    const int64_t total = (int64_t)n * m * l;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % n); const int64_t r = idx / n; const int j = (int)(r % m); const int k = (int)(r / m);
+        const cplx w = W[(o0 + i) + (int64_t)p0 * ((o1 + j) + (int64_t)p1 * (o2 + k))];
+        cplx v = make_double2(beta * w.x, beta * w.y);
+        if (alpha != 0.0) { const cplx xo = x[idx]; v.x = fma(alpha, xo.x, v.x); v.y = fma(alpha, xo.y, v.y); }
+        y[idx] = v;
+    }
+}
+
+void pw_embed(const cplx* x, const double* nu, cplx* W, const int dims[3], const int pads[3], hipStream_t st) {
+    const int64_t total = (int64_t)pads[0] * pads[1] * pads[2];
+    hipLaunchKernelGGL(k_embed, dim3(grid_for(total)), dim3(256), 0, st, x, nu, W, dims[0], dims[1], dims[2], pads[0], pads[1], pads[2]);
+    LSFC_HIP(hipGetLastError());
+}
+void pw_mul_inplace(cplx* W, const cplx* S, int64_t total, hipStream_t st) {
+    hipLaunchKernelGGL(k_mul_inplace, dim3(grid_for(total)), dim3(256), 0, st, W, S, total);
+    LSFC_HIP(hipGetLastError());
+}
+void pw_crop_axpy(const cplx* W, const cplx* x, cplx* y, double alpha, double beta, const int dims[3], const int pads[3],
+                  const int off[3], hipStream_t st) {
+    const int64_t total = (int64_t)dims[0] * dims[1] * dims[2];
+    hipLaunchKernelGGL(k_crop_axpy, dim3(grid_for(total)), dim3(256), 0, st, W, x, y, alpha, beta, dims[0], dims[1], dims[2],
+                       pads[0], pads[1], off[0], off[1], off[2]);
+    LSFC_HIP(hipGetLastError());
+}
+
+// ---- symbol preparation (plan creation only) --------------------------------
+
+// dst[i][j][k] = scale * src[(i+s0)%p0][(j+s1)%p1][(k+s2)%p2]   (ifftshift: s = p/2 for even p, (p+1)/2... caller passes)
+__global__ void k_roll_scale(const cplx* __restrict__ src, cplx* __restrict__ dst, int p0, int p1, int p2, int s0, int s1, int s2, double scale) {
+    const int64_t total = (int64_t)p0 * p1 * p2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % p0); const int64_t r = idx / p0; const int j = (int)(r % p1); const int k = (int)(r / p1);
+        const int si = (i + s0) % p0, sj = (j + s1) % p1, sk = (k + s2) % p2;
+        const cplx v = src[si + (int64_t)p0 * (sj + (int64_t)p1 * sk)];
+        dst[idx] = make_double2(scale * v.x, scale * v.y);
+    }
+}
+
+// Wrap-crop of the spatial kernel: dst on the (q0,q1,q2)=(2n,2m,2l) grid takes offsets
+// d in [-q/2, q/2) per axis from the (p0,p1,p2)-periodic src:  dst[d mod q] = scale*src[d mod p].
+__global__ void k_wrap_crop(const cplx* __restrict__ src, cplx* __restrict__ dst, int p0, int p1, int p2, int q0, int q1, int q2, double scale) {
+    const int64_t total = (int64_t)q0 * q1 * q2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % q0); const int64_t r = idx / q0; const int j = (int)(r % q1); const int k = (int)(r / q1);
+        const int si = (i < q0 / 2 || q0 == 1) ? i : i + (p0 - q0);
+        const int sj = (j < q1 / 2 || q1 == 1) ? j : j + (p1 - q1);
+        const int sk = (k < q2 / 2 || q2 == 1) ? k : k + (p2 - q2);
+        const cplx v = src[si + (int64_t)p0 * (sj + (int64_t)p1 * sk)];
+        dst[idx] = make_double2(scale * v.x, scale * v.y);
+    }
+}
+
+// Natural FFT-order symbol G2[Lx][Ly][Lz] -> storage-order, tile-interleaved layout of the
+// pruned pipeline.  3D: out[xi + 8*(sz + Lz*(sy + Ly*xb))];  2D (Lz==1): out[sx + Lx*sy].
+__global__ void k_permute_symbol(const cplx* __restrict__ G2, cplx* __restrict__ out, const int* __restrict__ px,
+                                 const int* __restrict__ py, const int* __restrict__ pz, int Lx, int Ly, int Lz, double scale) {
+    const int64_t total = (int64_t)Lx * Ly * Lz;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int sx, sy, sz;
+        if (Lz > 1) {
+            const int xi = (int)(idx % 8); int64_t r = idx / 8;
+            sz = (int)(r % Lz); r /= Lz; sy = (int)(r % Ly); const int xb = (int)(r / Ly);
+            sx = xb * 8 + xi;
+        } else { sx = (int)(idx % Lx); sy = (int)(idx / Lx); sz = 0; }
+        const int kx = px[sx], ky = py[sy], kz = (Lz > 1) ? pz[sz] : 0;
+        const cplx v = G2[kx + (int64_t)Lx * (ky + (int64_t)Ly * kz)];
+        out[idx] = make_double2(scale * v.x, scale * v.y);
+    }
+}
+
+__global__ void k_scale(cplx* __restrict__ a, double s, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        cplx v = a[idx]; a[idx] = make_double2(s * v.x, s * v.y);
+    }
+}
+
+void pw_roll_scale(const cplx* src, cplx* dst, const int p[3], const int s[3], double scale, hipStream_t st) {
+    const int64_t total = (int64_t)p[0] * p[1] * p[2];
+    hipLaunchKernelGGL(k_roll_scale, dim3(grid_for(total)), dim3(256), 0, st, src, dst, p[0], p[1], p[2], s[0], s[1], s[2], scale);
+    LSFC_HIP(hipGetLastError());
+}
+void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], double scale, hipStream_t st) {
+    const int64_t total = (int64_t)q[0] * q[1] * q[2];
+    hipLaunchKernelGGL(k_wrap_crop, dim3(grid_for(total)), dim3(256), 0, st, src, dst, p[0], p[1], p[2], q[0], q[1], q[2], scale);
+    LSFC_HIP(hipGetLastError());
+}
+void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* py, const int* pz, const int L[3], double scale, hipStream_t st) {
+    const int64_t total = (int64_t)L[0] * L[1] * L[2];
+    hipLaunchKernelGGL(k_permute_symbol, dim3(grid_for(total)), dim3(256), 0, st, G2, out, px, py, pz, L[0], L[1], L[2], scale);
+    LSFC_HIP(hipGetLastError());
+}
+void pw_scale(cplx* a, double s, int64_t total, hipStream_t st) {
+    hipLaunchKernelGGL(k_scale, dim3(grid_for(total)), dim3(256), 0, st, a, s, total);
+    LSFC_HIP(hipGetLastError());
+}
+
+// ---- GMRES BLAS-1 ------------------------------------------------------------
+// Reductions: each block accumulates a grid-stride slice, reduces across its four
+// waves (shuffle, then LDS), and writes one partial; a single-wave finisher sums
+// the partials in index order.  RED_BLOCKS is fixed so results do not depend on N
+// beyond the slice boundaries -> run-to-run bitwise reproducible.
+
+static constexpr int RED_BLOCKS = 1024;
+static constexpr int RED_THREADS = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ cplx block_sum(cplx acc, cplx* sh) {
+    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = acc;
+    __syncthreads();
+    cplx r = make_double2(0.0, 0.0);
+    if (threadIdx.x == 0) { for (int w = 0; w < RED_THREADS / 64; ++w) { r.x += sh[w].x; r.y += sh[w].y; } }
+    return r;   // valid in thread 0
+}
+
+// partial[b] = sum_i conj(a[i]) * b[i]   (Julia dot(a, b))
+__global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const cplx* __restrict__ a, const cplx* __restrict__ b, cplx* __restrict__ partial, int64_t n) {
+    __shared__ cplx sh[RED_THREADS / 64];
+    cplx acc = make_double2(0.0, 0.0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cplx u = a[i], v = b[i];
+        acc.x = fma(u.x, v.x, fma(u.y, v.y, acc.x));
+        acc.y = fma(u.x, v.y, fma(-u.y, v.x, acc.y));
+    }
+    const cplx r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// w -= h[hidx] * v, then partial[b] = sum conj(vnext) * w  (fused MGS step: one pass over w)
+__global__ __launch_bounds__(RED_THREADS) void k_axpy_dot_partial(cplx* __restrict__ w, const cplx* __restrict__ v, const cplx* __restrict__ h,
+                                                                   const cplx* __restrict__ vnext, cplx* __restrict__ partial, int64_t n) {
+    __shared__ cplx sh[RED_THREADS / 64];
+    const cplx c = *h;
+    cplx acc = make_double2(0.0, 0.0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cplx q = v[i]; cplx x = w[i];
+        x.x -= fma(c.x, q.x, -c.y * q.y);
+        x.y -= fma(c.x, q.y, c.y * q.x);
+        w[i] = x;
+        if (vnext) {
+            const cplx u = vnext[i];
+            acc.x = fma(u.x, x.x, fma(u.y, x.y, acc.x));
+            acc.y = fma(u.x, x.y, fma(-u.y, x.x, acc.y));
+        } else {   // last MGS step: accumulate |w|^2 for the norm
+            acc.x = fma(x.x, x.x, fma(x.y, x.y, acc.x));
+        }
+    }
+    const cplx r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// out = sum partial[0..count)   (mode 0) or sqrt(re sum) in out.x (mode 1)
+__global__ __launch_bounds__(64) void k_finish(const cplx* __restrict__ partial, int count, cplx* __restrict__ out, int mode) {
+    cplx acc = make_double2(0.0, 0.0);
+    for (int i = threadIdx.x; i < count; i += 64) { acc.x += partial[i].x; acc.y += partial[i].y; }
+    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y);
+    if (threadIdx.x == 0) { if (mode == 1) acc = make_double2(sqrt(acc.x), 0.0); *out = acc; }
+}
+
+// multi-dot for classical Gram-Schmidt: partial[j*RED_BLOCKS + b] = sum conj(V_j) * w, j < k (k <= 32 per launch)
+__global__ __launch_bounds__(RED_THREADS) void k_multidot_partial(const cplx* __restrict__ V, int64_t ldv, int k, const cplx* __restrict__ w,
+                                                                   cplx* __restrict__ partial, int64_t n) {
+    __shared__ cplx sh[RED_THREADS / 64];
+    for (int j = 0; j < k; ++j) {
+        const cplx* a = V + (int64_t)j * ldv;
+        cplx acc = make_double2(0.0, 0.0);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const cplx u = a[i], v = w[i];
+            acc.x = fma(u.x, v.x, fma(u.y, v.y, acc.x));
+            acc.y = fma(u.x, v.y, fma(-u.y, v.x, acc.y));
+        }
+        const cplx r = block_sum(acc, sh);
+        if (threadIdx.x == 0) partial[(int64_t)j * RED_BLOCKS + blockIdx.x] = r;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(64) void k_multifinish(const cplx* __restrict__ partial, int count, cplx* __restrict__ out) {
+    const cplx* p = partial + (int64_t)blockIdx.x * RED_BLOCKS;
+    cplx acc = make_double2(0.0, 0.0);
+    for (int i = threadIdx.x; i < count; i += 64) { acc.x += p[i].x; acc.y += p[i].y; }
+    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
+// y += sign * sum_j c[j] * V_j   (k <= 64 columns; coefficients in device memory)
+__global__ void k_gemv_acc(cplx* __restrict__ y, const cplx* __restrict__ V, int64_t ldv, int k, const cplx* __restrict__ c, double sign, int64_t n) {
+    __shared__ cplx cs[64];
+    if (threadIdx.x < k) cs[threadIdx.x] = c[threadIdx.x];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        cplx acc = make_double2(0.0, 0.0);
+        for (int j = 0; j < k; ++j) {
+            const cplx q = V[(int64_t)j * ldv + i], cj = cs[j];
+            acc.x += fma(cj.x, q.x, -cj.y * q.y);
+            acc.y += fma(cj.x, q.y, cj.y * q.x);
+        }
+        cplx v = y[i]; v.x = fma(sign, acc.x, v.x); v.y = fma(sign, acc.y, v.y); y[i] = v;
+    }
+}
+
+// y = a - b
+__global__ void k_sub(cplx* __restrict__ y, const cplx* __restrict__ a, const cplx* __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cplx u = a[i], v = b[i]; y[i] = make_double2(u.x - v.x, u.y - v.y);
+    }
+}
+// a *= 1 / s[0].x   (s on the device: no host round trip between the norm and the scaling)
+__global__ void k_scale_inv_dev(cplx* __restrict__ a, const cplx* __restrict__ s, int64_t n) {
+    const double inv = 1.0 / s->x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        cplx v = a[i]; a[i] = make_double2(v.x * inv, v.y * inv);
+    }
+}
+
+void blas_dot(const cplx* a, const cplx* b, cplx* partial, cplx* out, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_dot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, a, b, partial, n);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, 0);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_nrm2(const cplx* a, cplx* partial, cplx* out, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_dot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, a, a, partial, n);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, 1);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_axpy_dot(cplx* w, const cplx* v, const cplx* h, const cplx* vnext, cplx* partial, cplx* out, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_axpy_dot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, w, v, h, vnext, partial, n);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, vnext ? 0 : 1);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_multidot(const cplx* V, int64_t ldv, int k, const cplx* w, cplx* partial, cplx* out, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_multidot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, V, ldv, k, w, partial, n);
+    hipLaunchKernelGGL(k_multifinish, dim3(k), dim3(64), 0, st, partial, RED_BLOCKS, out);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_gemv_acc(cplx* y, const cplx* V, int64_t ldv, int k, const cplx* c, double sign, int64_t n, hipStream_t st) {
+    LSFC_REQUIRE(k <= 64, "gemv_acc: at most 64 columns");
+    hipLaunchKernelGGL(k_gemv_acc, dim3(grid_for(n)), dim3(256), 0, st, y, V, ldv, k, c, sign, n);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_sub(cplx* y, const cplx* a, const cplx* b, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_sub, dim3(grid_for(n)), dim3(256), 0, st, y, a, b, n);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_scale_inv_dev(cplx* a, const cplx* s, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_scale_inv_dev, dim3(grid_for(n)), dim3(256), 0, st, a, s, n);
+    LSFC_HIP(hipGetLastError());
+}
+int blas_partial_count() { return RED_BLOCKS * 64; }   // room for a 64-column multidot
+
+} // namespace lsfc

@@ -1,0 +1,25 @@
+// Host-side interface of the hand-written pruned axis passes (fft_kernels.hip).
+#pragma once
+#include "common.hpp"
+
+namespace lsfc {
+
+struct PrunedTuning {
+    bool split_x = true;   // contiguous (x) passes: exchange re/im separately (half the LDS, twice the barriers)
+    bool split_s = true;   // strided (y, z) passes
+};
+
+bool pruned_length_supported(int64_t L);
+// freq_of_storage[s] = frequency index held at storage index s after the forward pass of length L
+void pruned_perm(int L, int* freq_of_storage);
+PrunedTuning pruned_default_tuning();
+
+void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, hipStream_t);
+void pruned_xinv(int L, const PrunedTuning&, const cplx* in, const cplx* xorig, cplx* y, double alpha, double beta,
+                 const cplx* tw, int64_t nlines, hipStream_t);
+void pruned_yfwd(int L, const PrunedTuning&, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t);
+void pruned_yinv(int L, const PrunedTuning&, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t);
+void pruned_zfused(int L, const PrunedTuning&, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+                   int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, hipStream_t);
+
+} // namespace lsfc

@@ -1,0 +1,171 @@
+// Symbol generators: the builder side of the reference (buildFastConvolution*,
+// Gtruncated2D/3D, buildGConv) evaluated on the device (gfx950), setup-time only.
+#include "plan.hpp"
+#include "pointwise.hpp"
+#include <cmath>
+
+namespace lsfc {
+
+static inline unsigned grid_for(int64_t count, int block = 256, int cap = 256 * 16) {
+    int64_t g = (count + block - 1) / block; if (g < 1) g = 1; if (g > cap) g = cap; return (unsigned)g;
+}
+
+// ---- Gtruncated3D (src/Functions.jl:49-51) -----------------------------------
+__device__ __forceinline__ cplx gtrunc3d(double L, double k, double s, cplx eiLk, bool patch, cplx limit) {
+    if (patch && s == k) return limit;
+    const double t = L * s / 3.14159265358979323846;
+    const double snc = (t == 0.0) ? 1.0 : sinpi(t) / (3.14159265358979323846 * t);     // Julia sinc
+    // cos(L s) - i k L sinc
+    const double cr = cos(L * s), ci = -k * L * snc;
+    // -1 + e^{iLk} * (cr + i ci)
+    const double nr = -1.0 + (eiLk.x * cr - eiLk.y * ci);
+    const double ni = eiLk.x * ci + eiLk.y * cr;
+    const double den = k * k - s * s;
+    return make_double2(nr / den, ni / den);
+}
+
+// Planes jz in [z0, z0+C) of the literal symbol in FFT order: W[jx + P0*(jy + P1*c)]
+__global__ void k_gen_gv3d_planes(cplx* __restrict__ W, int P0, int P1, int P2, int z0, int C, double dk, double L, double k,
+                                  cplx eiLk, int patch, cplx limit) {
+    const int64_t total = (int64_t)P0 * P1 * C;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int jx = (int)(idx % P0); const int64_t r = idx / P0; const int jy = (int)(r % P1); const int jz = z0 + (int)(r / P1);
+        const double kx = dk * (double)(jx < P0 / 2 ? jx : jx - P0);
+        const double ky = dk * (double)(jy < P1 / 2 ? jy : jy - P1);
+        const double kz = dk * (double)(jz < P2 / 2 ? jz : jz - P2);
+        const double s = sqrt(kx * kx + ky * ky + kz * kz);       // src/FastConvolution3D.jl:98
+        W[idx] = gtrunc3d(L, k, s, eiLk, patch != 0, limit);
+    }
+}
+
+// U[dx + Q0*(dy + Q1*jz)] = W[wrap(dx) + P0*(wrap(dy) + P1*c)]  for the planes of one chunk
+__global__ void k_crop_xy_planes(const cplx* __restrict__ W, cplx* __restrict__ U, int P0, int P1, int Q0, int Q1, int z0, int C) {
+    const int64_t total = (int64_t)Q0 * Q1 * C;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int dx = (int)(idx % Q0); const int64_t r = idx / Q0; const int dy = (int)(r % Q1); const int c = (int)(r / Q1);
+        const int sx = dx < Q0 / 2 ? dx : dx + (P0 - Q0);
+        const int sy = dy < Q1 / 2 ? dy : dy + (P1 - Q1);
+        U[dx + (int64_t)Q0 * (dy + (int64_t)Q1 * (z0 + c))] = W[sx + (int64_t)P0 * (sy + (int64_t)P1 * c)];
+    }
+}
+
+// T2[dx + Q0*(dy + Q1*dz)] = scale * U[dx + Q0*(dy + Q1*wrap(dz))]
+__global__ void k_crop_z(const cplx* __restrict__ U, cplx* __restrict__ T2, int64_t plane, int P2, int Q2, double scale) {
+    const int64_t total = plane * Q2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t xy = idx % plane; const int dz = (int)(idx / plane);
+        const int sz = dz < Q2 / 2 ? dz : dz + (P2 - Q2);
+        const cplx v = U[xy + plane * sz];
+        T2[idx] = make_double2(scale * v.x, scale * v.y);
+    }
+}
+
+void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2) {
+    const int n = p->dims[0], m = p->dims[1], l = p->dims[2];
+    const int P0 = 4 * n, P1 = 4 * m, P2 = 4 * l, Q0 = 2 * n, Q1 = 2 * m, Q2 = 2 * l;
+    const double Lp = 4.0 * box, L = 1.8 * box, k = p->omega;       // src/FastConvolution3D.jl:72-73
+    const double dk = 2.0 * 3.14159265358979323846 / Lp;
+    const cplx eiLk = make_double2(cos(L * k), sin(L * k));
+    // analytic limit at s == k: (iL - (i/k) sin(Lk) e^{iLk}) / (2k)
+    const double sLk = sin(L * k);
+    const cplx limit = make_double2((sLk * eiLk.y / k) / (2.0 * k), (L - sLk * eiLk.x / k) / (2.0 * k));
+    const int patch = (p->flags & LSFC_FLAG_PATCH_SINGULAR) ? 1 : 0;
+    hipStream_t st = p->stream;
+
+    const int64_t plane_lit = (int64_t)P0 * P1, plane_red = (int64_t)Q0 * Q1;
+    // chunk of z-frequency planes: ~1 GiB of literal planes at a time
+    int C = (int)std::max<int64_t>(1, std::min<int64_t>(P2, ((int64_t)1 << 30) / (plane_lit * (int64_t)sizeof(cplx))));
+    while (P2 % C) --C;
+    DevBuf<cplx> U; U.alloc((size_t)(plane_red * P2));
+    {
+        DevBuf<cplx> W; W.alloc((size_t)(plane_lit * C));
+        const size_t len2[2] = { (size_t)P0, (size_t)P1 };
+        RocFft inv2d; inv2d.create(2, len2, false, (size_t)C);
+        for (int z0 = 0; z0 < P2; z0 += C) {
+            hipLaunchKernelGGL(k_gen_gv3d_planes, dim3(grid_for(plane_lit * C)), dim3(256), 0, st, W.p, P0, P1, P2, z0, C, dk, L, k, eiLk, patch, limit);
+            inv2d.exec(W.p, st);
+            hipLaunchKernelGGL(k_crop_xy_planes, dim3(grid_for(plane_red * C)), dim3(256), 0, st, W.p, U.p, P0, P1, Q0, Q1, z0, C);
+        }
+        LSFC_HIP(hipGetLastError());
+        LSFC_HIP(hipStreamSynchronize(st));
+    }
+    {
+        RocFft invz; invz.create_strided_1d((size_t)P2, (size_t)plane_red, 1, (size_t)plane_red, false);
+        invz.exec(U.p, st);
+        LSFC_HIP(hipStreamSynchronize(st));
+    }
+    G2.alloc((size_t)(plane_red * Q2));
+    hipLaunchKernelGGL(k_crop_z, dim3(grid_for(plane_red * Q2)), dim3(256), 0, st, U.p, G2.p, plane_red, P2, Q2,
+                       1.0 / ((double)P0 * (double)P1 * (double)P2));
+    LSFC_HIP(hipGetLastError());
+    LSFC_HIP(hipStreamSynchronize(st));
+    U.release();
+    const size_t len3[3] = { (size_t)Q0, (size_t)Q1, (size_t)Q2 };
+    RocFft fwd; fwd.create(3, len3, true);
+    fwd.exec(G2.p, st);
+    LSFC_HIP(hipStreamSynchronize(st));
+}
+
+// ---- Gtruncated2D (src/Functions.jl:40-42), centred literal (4n x 4m) ---------
+__global__ void k_gen_gv2d(cplx* __restrict__ G, int P0, int P1, double dk, double L, double k, cplx a, cplx b, int patch, cplx limit) {
+    const int64_t total = (int64_t)P0 * P1;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % P0), j = (int)(idx / P0);
+        const double kx = dk * (double)(i - P0 / 2), ky = dk * (double)(j - P1 / 2);       // kx = -(2n):(2n-1)
+        const double s = sqrt(kx * kx + ky * ky);
+        if (patch && s == k) { G[idx] = limit; continue; }
+        const double sj1 = s * j1(L * s), j0v = j0(L * s);
+        // 1 + a*(s J1(Ls)) - b*J0(Ls)
+        const double nr = 1.0 + a.x * sj1 - b.x * j0v, ni = a.y * sj1 - b.y * j0v;
+        const double den = s * s - k * k;
+        G[idx] = make_double2(nr / den, ni / den);
+    }
+}
+
+void symbol_gv2d_literal(lsfc_plan* p, double box, DevBuf<cplx>& G, int lit[3]) {
+    const int n = p->dims[0], m = p->dims[1];
+    lit[0] = 4 * n; lit[1] = 4 * m; lit[2] = 1;
+    const double Lp = 4.0 * box, L = 1.5 * box, k = p->omega;       // src/FastConvolution.jl:187-188
+    const double dk = 2.0 * 3.14159265358979323846 / Lp;
+    const double pi = 3.14159265358979323846;
+    // a = i pi/2 L H0(Lk), b = i pi/2 L k H1(Lk); H = J + iY
+    const double J0 = ::j0(L * k), Y0 = ::y0(L * k), J1 = ::j1(L * k), Y1 = ::y1(L * k);
+    const cplx a = make_double2(-pi / 2 * L * Y0, pi / 2 * L * J0);
+    const cplx b = make_double2(-pi / 2 * L * k * Y1, pi / 2 * L * k * J1);
+    // limit at s == k: (a L k J0(Lk) + b L J1(Lk)) / (2k)
+    const cplx limit = make_double2((a.x * L * k * J0 + b.x * L * J1) / (2 * k), (a.y * L * k * J0 + b.y * L * J1) / (2 * k));
+    G.alloc((size_t)lit[0] * lit[1]);
+    hipLaunchKernelGGL(k_gen_gv2d, dim3(grid_for((int64_t)lit[0] * lit[1])), dim3(256), 0, p->stream, G.p, lit[0], lit[1], dk, L, k, a, b,
+                       (p->flags & LSFC_FLAG_PATCH_SINGULAR) ? 1 : 0, limit);
+    LSFC_HIP(hipGetLastError());
+    LSFC_HIP(hipStreamSynchronize(p->stream));
+}
+
+// ---- buildGConv (src/FastConvolution.jl:425-469) ------------------------------
+__global__ void k_gen_trap2d(cplx* __restrict__ Ge, int P0, int P1, int n, int m, double xe0, double ye0, double h, double k, cplx d0) {
+    const int64_t total = (int64_t)P0 * P1;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % P0), j = (int)(idx / P0);
+        const double h2 = h * h;
+        if (i == n - 1 && j == m - 1) { Ge[idx] = make_double2(-0.25 * d0.y * h2, 0.25 * d0.x * h2); continue; }   // i/4 * D0 * h^2
+        const double xe = xe0 + h * i, ye = ye0 + h * j;
+        const double r = sqrt(xe * xe + ye * ye);
+        // i/4 * H0(k r) * h^2 = (-Y0 + i J0)/4 * h^2
+        Ge[idx] = make_double2(-0.25 * y0(k * r) * h2, 0.25 * j0(k * r) * h2);
+    }
+}
+
+void symbol_trap2d_literal(lsfc_plan* p, double x0, double y0, double h, cplx d0, DevBuf<cplx>& G) {
+    const int n = p->dims[0], m = p->dims[1];
+    const int P0 = 2 * n - 1, P1 = 2 * m - 1;
+    G.alloc((size_t)P0 * P1);
+    const double xe0 = x0 - (n - 1) / 2.0 * h, ye0 = y0 - (m - 1) / 2.0 * h;      // :433-434
+    hipLaunchKernelGGL(k_gen_trap2d, dim3(grid_for((int64_t)P0 * P1)), dim3(256), 0, p->stream, G.p, P0, P1, n, m, xe0, ye0, h, p->omega, d0);
+    LSFC_HIP(hipGetLastError());
+    const size_t len[2] = { (size_t)P0, (size_t)P1 };
+    RocFft fwd; fwd.create(2, len, true);
+    fwd.exec(G.p, p->stream);                                                       // GFFT = fft(Ge), :179
+    LSFC_HIP(hipStreamSynchronize(p->stream));
+}
+
+} // namespace lsfc

@@ -1,0 +1,209 @@
+/*
+ * lsfc.h -- C ABI of the MI355X-native Lippmann-Schwinger fast-convolution
+ * operator (y = x + omega^2 * G * (nu .* x)) and the GMRES loop that drives it.
+ *
+ * This is the drop-in boundary for ONE hot path of
+ * tanderson92/Fast_solver_Lippmann_Schwinger: the FastM / FastM3D operator
+ * apply and the IterativeSolvers.gmres! loop.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the Julia `ccall` stubs a maintainer would add.
+ *
+ * Conventions (identical to the reference):
+ *   - all grid functions are flat vectors in column-major order, x fastest
+ *     (examples/example.jl:39-40, examples/example3D.jl:33-39);
+ *   - complex numbers are interleaved (re, im) doubles == Julia Complex{Float64};
+ *   - every function returns 0 on success, a negative LSFC_E* code on failure;
+ *     the message is available through lsfc_last_error(); no C++ exception
+ *     crosses this boundary;
+ *   - a plan is not thread-safe; calls are synchronous on return for host
+ *     buffers and stream-ordered (plan stream) for device buffers.
+ *
+ * There is no CPU fallback behind this ABI: every compute entry point runs
+ * HIP kernels on a gfx950 device and fails with LSFC_ENODEV when none is present.
+ */
+#ifndef LSFC_H
+#define LSFC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lsfc_plan lsfc_plan;
+
+/* error codes */
+#define LSFC_OK        0
+#define LSFC_EINVAL   -1   /* bad argument (the reference would throw DimensionMismatch / UndefVarError) */
+#define LSFC_ENODEV   -2   /* no HIP device */
+#define LSFC_ENOMEM   -3
+#define LSFC_EHIP     -4   /* HIP / rocFFT / RCCL runtime failure */
+#define LSFC_ENOTCONV -5   /* GMRES hit maxiter without converging (x still updated, like gmres!) */
+
+/* quadRule (src/FastConvolution.jl:20, src/FastConvolution3D.jl:21) */
+#define LSFC_QUAD_TRAPEZOIDAL     0   /* "trapezoidal"    */
+#define LSFC_QUAD_GREENGARD_VICO  1   /* "Greengard_Vico" */
+
+/* where the caller's vectors live */
+#define LSFC_MEM_HOST    0
+#define LSFC_MEM_DEVICE  1
+
+/* plan flags */
+#define LSFC_FLAG_DEFAULT        0u
+#define LSFC_FLAG_LITERAL_PAD    1u   /* keep the reference's literal (ne,me,le) padded grid + shifts
+                                         (rocFFT path; for parity tests of the padding identity) */
+#define LSFC_FLAG_FORCE_ROCFFT   2u   /* reduced grid, but monolithic rocFFT transforms instead of
+                                         the hand-written pruned pipeline */
+#define LSFC_FLAG_PATCH_SINGULAR 4u   /* builders only: replace the removable 0/0 of the symbol at
+                                         |s| == k by its analytic limit (reference yields Inf/NaN) */
+
+/* orthogonalisation (IterativeSolvers.jl orth_meth) */
+#define LSFC_ORTH_MGS   0   /* ModifiedGramSchmidt() -- gmres! default */
+#define LSFC_ORTH_CGS   1   /* ClassicalGramSchmidt() */
+#define LSFC_ORTH_DGKS  2   /* DGKS() */
+
+/* ---- plan construction -------------------------------------------------- */
+
+/* Replaces the constructor FastM(GFFT,nu,ne,me,n,m,k; quadRule)
+ * (src/FastConvolution.jl:11-27).  gfft: ne*me interleaved complex, column-major,
+ * in the reference's layout: centred (fftshift) order for Greengard_Vico, plain
+ * FFT order for trapezoidal.  nu: n*m doubles.  Both are copied (host pointers). */
+int lsfc_plan_create_2d(lsfc_plan** out, int64_t n, int64_t m, int64_t ne, int64_t me,
+                        const double* nu, const double* gfft, double omega,
+                        int quad_rule, unsigned flags, int device);
+
+/* Replaces FastM3D(GFFT,nu,ne,me,le,n,m,l,k; quadRule) (src/FastConvolution3D.jl:7-26). */
+int lsfc_plan_create_3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l,
+                        int64_t ne, int64_t me, int64_t le,
+                        const double* nu, const double* gfft, double omega,
+                        int quad_rule, unsigned flags, int device);
+
+/* Replaces buildFastConvolution(x,y,h,k,nu; quadRule="Greengard_Vico")
+ * (src/FastConvolution.jl:170-236 + Gtruncated2D, src/Functions.jl:40-42).
+ * box = |x[end]-x[1]| + h; nu already evaluated on the grid (n*m doubles).
+ * The symbol is generated on the device. */
+int lsfc_plan_create_gv2d(lsfc_plan** out, int64_t n, int64_t m, double box, double omega,
+                          const double* nu, unsigned flags, int device);
+
+/* Replaces buildFastConvolution(x,y,h,k,nu; quadRule="trapezoidal")
+ * (src/FastConvolution.jl:172-183, buildGConv :425-469).  Odd n,m only, as the
+ * reference.  x0,y0 = x[1],y[1]; d0 = D[round(Int,k*h)] (re,im). */
+int lsfc_plan_create_trap2d(lsfc_plan** out, int64_t n, int64_t m, double x0, double y0, double h,
+                            double omega, double d0_re, double d0_im,
+                            const double* nu, unsigned flags, int device);
+
+/* Replaces buildFastConvolution3D(x,y,z,X,Y,Z,h,k,nu) (src/FastConvolution3D.jl:68-101
+ * + Gtruncated3D, src/Functions.jl:49-51).  The (4n)^3 symbol cube of the
+ * reference (137 GB at n=512) is never materialised: the symbol is evaluated
+ * slab-wise on the device and reduced to the equivalent (2n)^3 grid. */
+int lsfc_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega,
+                          const double* nu, unsigned flags, int device);
+
+int lsfc_plan_destroy(lsfc_plan* plan);
+
+/* ---- operator traits (src/FastConvolution.jl:31-41) ----------------------- */
+
+/* size(M, dim) == length(nu) */
+int64_t lsfc_plan_size(const lsfc_plan* plan);
+/* dims[0..2] = n,m,l (l = 1 in 2D); pads[0..2] = working padded grid actually used */
+int lsfc_plan_dims(const lsfc_plan* plan, int64_t dims[3], int64_t pads[3]);
+/* name of the transform pipeline in use: "pruned-hip", "rocfft-reduced", "rocfft-literal" */
+const char* lsfc_plan_pipeline(const lsfc_plan* plan);
+/* replace the contrast (nu is a mutable field of the reference struct) */
+int lsfc_plan_set_nu(lsfc_plan* plan, const double* nu, int memspace);
+/* copy the working symbol out (debug / tests): count complex entries written */
+int lsfc_plan_get_symbol(const lsfc_plan* plan, double* out, int64_t capacity_complex, int64_t* count);
+
+/* ---- the apply ------------------------------------------------------------ */
+
+/* y = x + omega^2 * FFTconvolution(nu .* x): replaces `*`, `mul!`, `fastconvolution`
+ * (src/FastConvolution.jl:43-107) and `*(M::FastM3D,b)` (src/FastConvolution3D.jl:31-37).
+ * x, y: N interleaved complex; y may alias x. */
+int lsfc_apply(lsfc_plan* plan, const double* x, double* y, int memspace);
+
+/* y = crop(ifft(GFFT .* fft(pad(apply_nu ? nu.*x : x)))): replaces FFTconvolution
+ * (src/FastConvolution.jl:110-154, src/FastConvolution3D.jl:39-63).  The reference
+ * multiplies by nu in the 2D trapezoidal branch only; the host wrapper passes
+ * apply_nu accordingly. */
+int lsfc_convolve(lsfc_plan* plan, const double* x, double* y, int apply_nu, int memspace);
+
+/* nrhs independent applies, vectors stored back to back (x + j*N).  Serves the
+ * multi-source callers (sampleG3D, src/FastConvolution3D.jl:136-160). */
+int lsfc_apply_batch(lsfc_plan* plan, const double* x, double* y, int64_t nrhs, int mode /*0 apply,1 convolve,2 convolve+nu*/, int memspace);
+
+/* ---- GMRES ---------------------------------------------------------------- */
+
+/* In-place left preconditioner, mirrors the two-argument ldiv!(Pl, v)
+ * (src/preconditioner.jl:147-170): v holds N interleaved complex on the HOST and
+ * is overwritten with Pl \ v.  Called synchronously on the calling thread once
+ * per Arnoldi step (and once per (re)start).  Return non-zero to abort. */
+typedef int (*lsfc_precond_fn)(void* user, double* v, int64_t n);
+
+typedef struct lsfc_gmres_opts {
+    int     restart;       /* <=0: min(20, N)                       */
+    int64_t maxiter;       /* <=0: N                                 */
+    double  reltol;        /* <0: sqrt(eps)                          */
+    double  abstol;        /* default 0                              */
+    int     orth;          /* LSFC_ORTH_*                            */
+    int     initially_zero;/* skip the initial A*x0 (x0 == 0)        */
+    lsfc_precond_fn precond; void* precond_user;  /* NULL: Identity() */
+} lsfc_gmres_opts;
+
+typedef struct lsfc_gmres_result {
+    int64_t iters;         /* inner iterations performed (history.iters)            */
+    int64_t mvps;          /* operator applications (history.mvps)                  */
+    int     converged;     /* history.isconverged                                   */
+    double  final_resnorm; /* last implicit (preconditioned) residual norm          */
+} lsfc_gmres_result;
+
+/* Replaces IterativeSolvers.gmres!(x, fastconv, b; Pl, restart, reltol, abstol,
+ * maxiter, log=true) as called at examples/example.jl:85,91 and
+ * examples/example3D.jl:78.  x (in/out) and b: N complex.  resnorm (may be NULL)
+ * receives up to resnorm_cap entries of history[:resnorm]. */
+int lsfc_gmres(lsfc_plan* plan, double* x, const double* b, const lsfc_gmres_opts* opts,
+               double* resnorm, int64_t resnorm_cap, lsfc_gmres_result* result, int memspace);
+
+/* ---- streams, timing, profiling ------------------------------------------ */
+
+/* Run the plan on a caller-owned hipStream_t (NULL = the legacy default stream). */
+int lsfc_plan_set_stream(lsfc_plan* plan, void* hip_stream);
+/* Block until all work queued by this plan has finished. */
+int lsfc_plan_synchronize(lsfc_plan* plan);
+/* Time `reps` back-to-back device-resident applies with HIP events recorded on the
+ * plan's stream; *ms_total = elapsed milliseconds for all reps. */
+int lsfc_time_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int reps, double* ms_total);
+/* Per-kernel timing of one device-resident apply: HIP events around every stage.
+ * names[i] (static strings), ms[i], bytes[i] = algorithmic HBM bytes of stage i. */
+int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int reps,
+                       int max_stages, const char** names, double* ms, double* bytes, int* nstages);
+
+/* ---- device memory helpers for hosts without a HIP binding ---------------- */
+int lsfc_device_count(int* count);
+int lsfc_malloc(void** dptr, size_t bytes, int device);
+int lsfc_free(void* dptr);
+int lsfc_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int lsfc_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- slab-distributed 3D operator (one process per GPU, RCCL over xGMI) ---- */
+
+/* 128-byte RCCL unique id: rank 0 calls lsfc_dist_unique_id and ships the bytes to
+ * the other ranks with whatever the host already has (torch.distributed, MPI, a file). */
+#define LSFC_UNIQUE_ID_BYTES 128
+int lsfc_dist_unique_id(unsigned char id[LSFC_UNIQUE_ID_BYTES]);
+
+/* z-slab-partitioned counterpart of lsfc_plan_create_gv3d: this rank owns planes
+ * k in [rank*l/nranks, (rank+1)*l/nranks) of nu, x and y.  The padded-grid transform is
+ * X-pass -> all-to-all -> Y,Z,symbol,Z^-1,Y^-1 -> all-to-all -> X^-1. */
+int lsfc_dist_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega,
+                               const double* nu_local, unsigned flags, int device,
+                               int rank, int nranks, const unsigned char id[LSFC_UNIQUE_ID_BYTES]);
+
+/* ---- errors ---------------------------------------------------------------- */
+const char* lsfc_last_error(void);
+const char* lsfc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSFC_H */

@@ -1,0 +1,67 @@
+"""Seeded parity cases shared by the golden generator, the oracle tests and the GPU tests.
+Inputs are regenerated from seeds (numpy PCG64 streams are stable across versions); the
+golden files hold the oracle's outputs only."""
+import numpy as np
+
+from oracle import lsfc_oracle as o
+
+TOL = 1e-10          # BASELINE.json north_star: <= 1e-10 relative l2 vs the CPU reference
+
+
+def nu_synthetic(dim, seed=1234):
+    """sum of 8 Gaussians, centres U(-.3,.3)^d, amplitudes U(-.3,.3), beta U(20,80)."""
+    rng = np.random.default_rng(seed)
+    cen = rng.uniform(-0.3, 0.3, size=(8, dim))
+    amp = rng.uniform(-0.3, 0.3, size=8)
+    beta = rng.uniform(20, 80, size=8)
+
+    def nu(*coords):
+        out = np.zeros_like(coords[0])
+        for c, a, b in zip(cen, amp, beta):
+            r2 = sum((x - ci) ** 2 for x, ci in zip(coords, c))
+            out = out + a * np.exp(-b * r2)
+        return out
+    return nu
+
+
+def grid(n, inclusive):
+    if inclusive:                      # examples/example.jl:35-36
+        h = 1.0 / (n - 1)
+        return -0.5 + h * np.arange(n), h
+    h = 1.0 / n                        # examples/example3D.jl:27-29
+    return -0.5 + h * np.arange(n), h
+
+
+def case_2d(name):
+    """-> dict(x, h, k, nu, quadRule, M (oracle FastM), b)"""
+    spec = {
+        "trap21":  dict(n=21, inclusive=True, k=None, quad="trapezoidal", nu=o.gaussian_bump),
+        "gv33":    dict(n=33, inclusive=True, k=None, quad="Greengard_Vico", nu=o.gaussian_bump),
+        "gv32":    dict(n=32, inclusive=False, k=20.0, quad="Greengard_Vico", nu=nu_synthetic(2)),
+        "gv128":   dict(n=128, inclusive=True, k=10 * np.pi, quad="Greengard_Vico", nu=o.gaussian_bump),   # BASELINE configs[0]
+    }[name]
+    x, h = grid(spec["n"], spec["inclusive"])
+    k = spec["k"] if spec["k"] is not None else 1.0 / h
+    M = o.build_fast_convolution(x, x, h, k, spec["nu"], quadRule=spec["quad"])
+    b = o.random_vector(spec["n"] ** 2)
+    return dict(x=x, h=h, k=k, nu=spec["nu"], quadRule=spec["quad"], M=M, b=b, n=spec["n"])
+
+
+def case_3d(name):
+    spec = {
+        "gv16":   dict(n=16, k=None, nu=o.gaussian_bump),
+        "gv16k10": dict(n=16, k=10.0, nu=nu_synthetic(3)),
+        "gv32":   dict(n=32, k=None, nu=o.gaussian_bump),
+        "gv32k10": dict(n=32, k=10.0, nu=nu_synthetic(3)),
+    }[name]
+    n = spec["n"]
+    x, h = grid(n, False)
+    k = spec["k"] if spec["k"] is not None else 1.0 / h
+    X, Y, Z = o.grid3d(x, x, x)
+    M = o.build_fast_convolution3d(x, x, x, X, Y, Z, h, k, spec["nu"])
+    b = o.random_vector(n ** 3)
+    return dict(x=x, h=h, k=k, nu=spec["nu"], M=M, b=b, n=n, X=X, Y=Y, Z=Z)
+
+
+def plane_wave(k, X):
+    return np.exp(1j * k * X)

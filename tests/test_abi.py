@@ -1,0 +1,63 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/lsfc.h declares, and the host mirror fails loudly (never silently falls back) when
+there is no GPU.  No compute is attempted here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lsfc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lsfc_[a-z0-9_]+)\s*\(", text)) - {"lsfc_precond_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    import fast_solver_lippmann_schwinger_amd._lib as L
+    lib = ctypes.CDLL(L.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/lsfc.h but not exported"
+    assert sorted(L.SIGNATURES) == names, "python binding and header disagree"
+
+
+def test_header_compiles_as_c():
+    src = '#include "lsfc.h"\nint main(void){ lsfc_gmres_opts o; (void)o; return LSFC_OK; }\n'
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"],
+                       input=src.encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import fast_solver_lippmann_schwinger_amd as pkg
+    pkg.load()
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(pkg.LsfcError) as ei:
+        pkg.FastM(np.zeros((4, 4), complex), np.zeros(4), 4, 4, 2, 2, 1.0, quadRule="Greengard_Vico")
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+
+
+def test_product_does_not_import_oracle():
+    pk = os.path.join(ROOT, "fast_solver_lippmann_schwinger_amd")
+    for dirpath, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("CPU oracle", ""), f"{f} mentions the oracle"
+
+
+def test_host_mirror_argument_errors():
+    import fast_solver_lippmann_schwinger_amd as pkg
+    with pytest.raises(NameError):       # reference: UndefVarError at src/FastConvolution.jl:106
+        pkg.FastM(np.zeros((4, 4), complex), np.zeros(4), 4, 4, 2, 2, 1.0, quadRule="Simpson")
+    with pytest.raises(ValueError):      # reference: DimensionMismatch from GFFT .* BFft
+        pkg.FastM(np.zeros((5, 4), complex), np.zeros(4), 4, 4, 2, 2, 1.0, quadRule="Greengard_Vico")
+    x, w = pkg.referenceValsTrapRule()
+    assert x[0] == 1.0 and w[0] == 1 - 0.892j and len(w) == 6

@@ -1,0 +1,210 @@
+"""GPU parity tests: the HIP operator, called through the C ABI (ctypes), against the CPU
+oracle on identical seeded inputs and against the committed golden vectors.
+Tolerance: <= 1e-10 relative l2 (BASELINE.json north_star); observed ~1e-15."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import lsfc_oracle as o
+import cases
+from cases import TOL
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+LITERAL, FORCE_ROCFFT, PATCH = 1, 2, 4
+
+
+# ---------------------------------------------------------------------------- 2D, literal-symbol constructor
+@pytest.mark.parametrize("name,flags,pipeline", [
+    ("trap21", 0, "rocfft-literal"),
+    ("gv33", 0, "rocfft-reduced"),
+    ("gv33", LITERAL, "rocfft-literal"),
+    ("gv32", 0, "pruned-hip"),
+    ("gv32", FORCE_ROCFFT, "rocfft-reduced"),
+    ("gv32", LITERAL, "rocfft-literal"),
+    ("gv128", 0, "pruned-hip"),
+])
+def test_fastm_2d_matches_oracle_and_golden(lsfc, name, flags, pipeline):
+    c = cases.case_2d(name)
+    Mo, b = c["M"], c["b"]
+    M = lsfc.FastM(Mo.GFFT, Mo.nu, Mo.ne, Mo.me, Mo.n, Mo.m, Mo.omega, quadRule=Mo.quadRule, flags=flags)
+    assert M.pipeline == pipeline
+    g = np.load(os.path.join(GOLD, f"2d_{name}.npz"))
+    y = M * b
+    assert rel_err(y, o.fastconvolution(Mo, b)) < TOL
+    assert rel_err(y, g["apply_random"]) < TOL
+    assert rel_err(lsfc.FFTconvolution(M, b), g["conv_random"]) < TOL
+    X, _ = o.grid2d(c["x"], c["x"])
+    assert rel_err(lsfc.fastconvolution(M, cases.plane_wave(c["k"], X)), g["apply_planewave"]) < TOL
+    # traits (src/FastConvolution.jl:31-41) and mul!
+    N = Mo.n * Mo.m
+    assert lsfc.size(M, 1) == N and lsfc.size(M) == ((N,), (N,)) and lsfc.eltype(M) == np.complex128
+    Y = np.empty(N, complex)
+    lsfc.mul_(Y, M, b)
+    assert np.array_equal(Y, y)
+    # run-to-run bitwise reproducibility (no float atomics anywhere in the apply)
+    assert np.array_equal(M * b, y)
+
+
+# ---------------------------------------------------------------------------- 3D, literal-symbol constructor
+@pytest.mark.parametrize("name,flags", [("gv16", 0), ("gv16", FORCE_ROCFFT), ("gv16", LITERAL), ("gv16k10", 0), ("gv32", 0), ("gv32k10", 0)])
+def test_fastm3d_matches_oracle_and_golden(lsfc, name, flags):
+    c = cases.case_3d(name)
+    Mo, b, n = c["M"], c["b"], c["n"]
+    M = lsfc.FastM3D(Mo.GFFT, Mo.nu, Mo.ne, Mo.me, Mo.le, n, n, n, Mo.omega, flags=flags)
+    assert M.pipeline == {0: "pruned-hip", FORCE_ROCFFT: "rocfft-reduced", LITERAL: "rocfft-literal"}[flags]
+    g = np.load(os.path.join(GOLD, f"3d_{name}.npz"))
+    y = M * b
+    assert rel_err(y, g["apply_random"]) < TOL
+    if "conv_random" in g:
+        assert rel_err(lsfc.FFTconvolution(M, b), g["conv_random"]) < TOL
+        assert rel_err(M * cases.plane_wave(c["k"], c["X"]), g["apply_planewave"]) < TOL
+    assert np.array_equal(M * b, y)
+
+
+def test_noncubic_3d_pruned(lsfc):
+    # distinct n, m, l exercise every stride of the tiled intermediate layouts
+    n, m, l = 16, 32, 64
+    rng = np.random.default_rng(7)
+    G = rng.standard_normal((4 * n, 4 * m, 4 * l)) + 1j * rng.standard_normal((4 * n, 4 * m, 4 * l))
+    nu = rng.uniform(-0.3, 0.3, n * m * l)
+    b = o.random_vector(n * m * l)
+    k = 7.0
+    G2 = o.reduce_symbol(G, (n, m, l))
+    ref = o.apply_reduced(G2, nu, k, b, (n, m, l))
+    for flags, pipe in [(0, "pruned-hip"), (FORCE_ROCFFT, "rocfft-reduced"), (LITERAL, "rocfft-literal")]:
+        M = lsfc.FastM3D(G, nu, 4 * n, 4 * m, 4 * l, n, m, l, k, flags=flags)
+        assert M.pipeline == pipe
+        assert rel_err(M * b, ref) < TOL, pipe
+        assert rel_err(lsfc.FFTconvolution(M, b), o.convolve_reduced(G2, b, (n, m, l))) < TOL, pipe
+
+
+def test_noncubic_2d_pruned(lsfc):
+    n, m = 64, 16
+    rng = np.random.default_rng(8)
+    G = rng.standard_normal((4 * n, 4 * m)) + 1j * rng.standard_normal((4 * n, 4 * m))
+    nu = rng.uniform(-0.3, 0.3, n * m)
+    b = o.random_vector(n * m)
+    G2 = o.reduce_symbol(G, (n, m))
+    M = lsfc.FastM(G, nu, 4 * n, 4 * m, n, m, 3.0, quadRule="Greengard_Vico")
+    assert M.pipeline == "pruned-hip"
+    assert rel_err(M * b, o.apply_reduced(G2, nu, 3.0, b, (n, m))) < TOL
+    with pytest.raises(ValueError):           # the reference's FFTconvolution(::FastM) assumes n == m
+        lsfc.FFTconvolution(M, b)
+
+
+@pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 1024])
+def test_every_line_length_2d(lsfc, n):
+    # one case per hand-written factorisation (padded length 2n = 32 ... 2048), random symbol
+    rng = np.random.default_rng(100 + n)
+    G2 = rng.standard_normal((2 * n, 2 * n)) + 1j * rng.standard_normal((2 * n, 2 * n))
+    # hand the kernel a literal symbol whose reduction is G2: centred 2n grid (ne == 2n is allowed)
+    G = np.fft.fftshift(G2)
+    nu = rng.uniform(-0.3, 0.3, n * n)
+    b = o.random_vector(n * n)
+    M = lsfc.FastM(G, nu, 2 * n, 2 * n, n, n, 2.0, quadRule="Greengard_Vico")
+    assert M.pipeline == "pruned-hip" and M.padded_dims[:2] == (2 * n, 2 * n)
+    assert rel_err(M * b, o.apply_reduced(G2, nu, 2.0, b, (n, n))) < TOL
+
+
+# ---------------------------------------------------------------------------- builders (symbol generated on the device)
+@pytest.mark.parametrize("name", ["trap21", "gv33", "gv32", "gv128"])
+def test_build_fast_convolution_2d(lsfc, name):
+    c = cases.case_2d(name)
+    M = lsfc.buildFastConvolution(c["x"], c["x"], c["h"], c["k"], c["nu"], quadRule=c["quadRule"])
+    g = np.load(os.path.join(GOLD, f"2d_{name}.npz"))
+    assert rel_err(M * c["b"], g["apply_random"]) < TOL
+    assert rel_err(lsfc.FFTconvolution(M, c["b"]), g["conv_random"]) < TOL
+    assert (M.ne, M.n) == (c["M"].ne, c["M"].n)
+
+
+@pytest.mark.parametrize("name", ["gv16", "gv16k10", "gv32", "gv32k10"])
+def test_build_fast_convolution_3d(lsfc, name):
+    c = cases.case_3d(name)
+    M = lsfc.buildFastConvolution3D(c["x"], c["x"], c["x"], c["X"], c["Y"], c["Z"], c["h"], c["k"], c["nu"])
+    assert M.pipeline == "pruned-hip"
+    g = np.load(os.path.join(GOLD, f"3d_{name}.npz"))
+    assert rel_err(M * c["b"], g["apply_random"]) < TOL
+
+
+def test_builder_3d_n128_against_slabwise_oracle(lsfc):
+    n = 128
+    x, h = cases.grid(n, False)
+    k = 1.0 / h
+    X, Y, Z = o.grid3d(x, x, x)
+    nuv = cases.nu_synthetic(3)(X, Y, Z)
+    M = lsfc.buildFastConvolution3D(x, x, x, X, Y, Z, h, k, nuv)
+    G2 = o.reduced_symbol_gv3d(n, n, n, 1.0, k, patch_singular=False)
+    b = o.random_vector(n ** 3)
+    assert rel_err(M * b, o.apply_reduced(G2, nuv, k, b, (n, n, n))) < TOL
+
+
+def test_singular_omega_patch(lsfc):
+    # omega = 8 pi on the half-open unit box with n = 16: lattice points sit exactly on |s| = k.
+    # Unpatched the reference (and this build) produce non-finite output; PATCH uses the analytic limit.
+    n = 16
+    x, h = cases.grid(n, False)
+    k = 8 * np.pi
+    X, Y, Z = o.grid3d(x, x, x)
+    b = o.random_vector(n ** 3)
+    Mo = o.build_fast_convolution3d(x, x, x, X, Y, Z, h, k, o.gaussian_bump, patch_singular=True)
+    assert np.isfinite(Mo.GFFT).all()
+    with np.errstate(all="ignore"):
+        assert not np.isfinite(o.build_fast_convolution3d(x, x, x, X, Y, Z, h, k, o.gaussian_bump).GFFT).all()
+    M = lsfc.buildFastConvolution3D(x, x, x, X, Y, Z, h, k, o.gaussian_bump, flags=PATCH)
+    assert rel_err(M * b, o.mul(Mo, b)) < TOL
+    Mbad = lsfc.buildFastConvolution3D(x, x, x, X, Y, Z, h, k, o.gaussian_bump)
+    assert not np.isfinite(Mbad * b).all()
+
+
+# ---------------------------------------------------------------------------- properties and callers
+def test_analytic_gaussian_known_answer(lsfc):
+    n, k, sig = 64, 10.0, 0.05
+    x, h = cases.grid(n, False)
+    X, Y, Z = o.grid3d(x, x, x)
+    M = lsfc.buildFastConvolution3D(x, x, x, X, Y, Z, h, k, o.gaussian_bump)
+    f = (np.exp(-(X**2 + Y**2 + Z**2) / (2 * sig**2)) / ((2 * np.pi) ** 1.5 * sig**3)).astype(complex)
+    with np.errstate(all="ignore"):
+        ref = -o.sol_ref_helmholtz(X, Y, Z, sig, k)
+    ok = np.isfinite(ref)
+    assert rel_err(lsfc.FFTconvolution(M, f)[ok], ref[ok]) < 1e-10
+
+
+def test_sample_g3d_delta_sources(lsfc):
+    c = cases.case_3d("gv16")
+    Mo, n = c["M"], c["n"]
+    M = lsfc.FastM3D(Mo.GFFT, Mo.nu, Mo.ne, Mo.me, Mo.le, n, n, n, Mo.omega)
+    indS = [0, 17, n**3 - 1, 5 + n * (6 + n * 7)]
+    assert rel_err(lsfc.sampleG3D(Mo.omega, None, None, None, indS, M), o.sample_g_conv(indS, Mo)) < TOL
+
+
+def test_set_nu_and_aliasing(lsfc):
+    c = cases.case_3d("gv16")
+    Mo, b, n = c["M"], c["b"], c["n"]
+    M = lsfc.FastM3D(Mo.GFFT, Mo.nu, Mo.ne, Mo.me, Mo.le, n, n, n, Mo.omega)
+    nu2 = cases.nu_synthetic(3)(c["X"], c["Y"], c["Z"])
+    M.set_nu(nu2)
+    Mo.nu = nu2
+    ref = o.mul(Mo, b)
+    assert rel_err(M * b, ref) < TOL
+    y = b.copy()
+    M.mul_(y, y)                       # y may alias x
+    assert rel_err(y, ref) < TOL
+
+
+def test_device_resident_vectors_torch(lsfc):
+    import torch
+    c = cases.case_3d("gv16")
+    Mo, b, n = c["M"], c["b"], c["n"]
+    M = lsfc.FastM3D(Mo.GFFT, Mo.nu, Mo.ne, Mo.me, Mo.le, n, n, n, Mo.omega)
+    xb = torch.from_numpy(b).cuda()
+    y = M * xb
+    assert y.is_cuda
+    M.synchronize()
+    assert rel_err(y.cpu().numpy(), o.mul(Mo, b)) < TOL
+    ms = lsfc.time_apply(M, xb, y, 3)
+    assert ms > 0
+    prof = lsfc.profile_apply(M, xb, y, 2)
+    assert [p[0] for p in prof] == ["xfwd", "yfwd", "zfused", "yinv", "xinv"]
