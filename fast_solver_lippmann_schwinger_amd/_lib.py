@@ -78,6 +78,12 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback for the lsfc operator")
+        try:
+            # PyTorch-ROCm bundles its own HIP runtime; when both live in one process torch's copy must be
+            # loaded first, otherwise torch.cuda later reports "No HIP GPUs are available".
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -10,6 +10,15 @@ static inline unsigned grid_for(int64_t count, int block = 256, int cap = 256 * 
     int64_t g = (count + block - 1) / block; if (g < 1) g = 1; if (g > cap) g = cap; return (unsigned)g;
 }
 
+// a*a - b*b without FMA contraction (HIP's __dmul_rn is a plain product and still contracts): at
+// |s| == k the reference divides by an exact zero and yields Inf/NaN; keep that behaviour bit for bit.
+__device__ __forceinline__ double diff_squares_exact(double a, double b) {
+#pragma clang fp contract(off)
+    const double aa = a * a;
+    const double bb = b * b;
+    return aa - bb;
+}
+
 // ---- Gtruncated3D (src/Functions.jl:49-51) -----------------------------------
 __device__ __forceinline__ cplx gtrunc3d(double L, double k, double s, cplx eiLk, bool patch, cplx limit) {
     if (patch && s == k) return limit;
@@ -20,7 +29,7 @@ __device__ __forceinline__ cplx gtrunc3d(double L, double k, double s, cplx eiLk
     // -1 + e^{iLk} * (cr + i ci)
     const double nr = -1.0 + (eiLk.x * cr - eiLk.y * ci);
     const double ni = eiLk.x * ci + eiLk.y * cr;
-    const double den = k * k - s * s;
+    const double den = diff_squares_exact(k, s);
     return make_double2(nr / den, ni / den);
 }
 
@@ -117,7 +126,7 @@ __global__ void k_gen_gv2d(cplx* __restrict__ G, int P0, int P1, double dk, doub
         const double sj1 = s * j1(L * s), j0v = j0(L * s);
         // 1 + a*(s J1(Ls)) - b*J0(Ls)
         const double nr = 1.0 + a.x * sj1 - b.x * j0v, ni = a.y * sj1 - b.y * j0v;
-        const double den = s * s - k * k;
+        const double den = diff_squares_exact(s, k);
         G[idx] = make_double2(nr / den, ni / den);
     }
 }

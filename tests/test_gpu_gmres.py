@@ -29,8 +29,12 @@ def test_gmres_history_matches_golden(lsfc):
     u = np.zeros(M.N, complex)
     u, hist = lsfc.gmres_(u, M, rhs, restart=10, maxiter=20, reltol=1e-12, log=True)
     r = hist["resnorm"]
-    assert len(r) == len(g["resnorm"]) == 20 and hist.mvps == int(g["mvps"])
-    assert np.max(np.abs(r - g["resnorm"]) / g["resnorm"]) < 1e-6
+    assert len(r) == len(g["resnorm"]) == 13 and hist.mvps == int(g["mvps"])
+    # after a restart beta is recomputed from the true residual, whose cancellation error is ~eps*|b|:
+    # compare to 1e-6 while the residual is well above that floor, 1e-3 below it
+    rel = np.abs(r - g["resnorm"]) / g["resnorm"]
+    big = g["resnorm"] > 1e-8 * g["resnorm"][0]
+    assert np.max(rel[big]) < 1e-6 and np.max(rel) < 1e-3
     assert rel_err(u, g["u"]) < 1e-8
 
 
