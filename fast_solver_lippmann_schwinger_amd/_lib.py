@@ -55,6 +55,7 @@ SIGNATURES = {
     "lsfc_gmres": (_I, [_P, _P, _P, C.POINTER(GmresOpts), _P, _L, C.POINTER(GmresResult), _I]),
     "lsfc_plan_set_stream": (_I, [_P, _P]),
     "lsfc_plan_synchronize": (_I, [_P]),
+    "lsfc_plan_set_tuning": (_I, [_P, C.c_char_p, _I]),
     "lsfc_time_apply": (_I, [_P, _P, _P, _I, C.POINTER(_D)]),
     "lsfc_profile_apply": (_I, [_P, _P, _P, _I, _I, C.POINTER(C.c_char_p), C.POINTER(_D), C.POINTER(_D), C.POINTER(_I)]),
     "lsfc_device_count": (_I, [C.POINTER(_I)]),
@@ -64,6 +65,8 @@ SIGNATURES = {
     "lsfc_memcpy_d2h": (_I, [_P, _P, C.c_size_t]),
     "lsfc_dist_unique_id": (_I, [_P]),
     "lsfc_dist_plan_create_gv3d": (_I, [_PP, _L, _L, _L, _D, _D, _P, _U, _I, _I, _I, _P]),
+    "lsfc_dist_sim_plan_create_gv3d": (_I, [_PP, _L, _L, _L, _D, _D, _P, _U, _I, _I, _I]),
+    "lsfc_dist_sim_apply": (_I, [_PP, _I, _PP, _PP, _I]),
     "lsfc_last_error": (C.c_char_p, []),
     "lsfc_version": (C.c_char_p, []),
 }

@@ -1,13 +1,219 @@
-// Slab-distributed 3D operator over RCCL (one process per GPU).  Filled in below.
+// Slab-distributed 3D operator: one process per GPU, RCCL over xGMI.
+//
+// Rank p owns z planes [p*lz, (p+1)*lz) of x, y and nu.  Per apply:
+//   phase 1 (local)   k_xfwd on the own planes; the output is written already packed per destination
+//                     rank: S1[q][W][m][lz], W = Lx/P storage indices of x' for rank q
+//   exchange 1        all-to-all (grouped ncclSend/ncclRecv): block q of S1 -> rank q.  The received blocks,
+//                     ordered by source rank, ARE the natural array R1[W][m][l] (blocks concatenate along z)
+//   phase 2 (local)   k_yfwd, k_zfused (symbol slab of the own x' tiles), k_yinv on R1 / A2
+//   exchange 2        block p of R1 (z range of rank p) -> rank p, received into S1[q][W][m][lz]
+//   phase 3 (local)   k_xinv reads that packed layout directly, y = alpha*x + beta*(.)
+// No pack/unpack/transposition kernel runs: the chunked addressing of the x passes does the packing,
+// and the exchange moves 2N complex per transpose, the minimum-volume point of the pipeline.
 #include "plan.hpp"
-namespace lsfc { DistState::~DistState() {} }
+#include "pointwise.hpp"
+#include <rccl/rccl.h>
+#include <cstring>
+#include <vector>
+
+namespace lsfc {
+
+#define LSFC_NCCL(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) \
+    ::lsfc::fail(LSFC_EHIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); } while (0)
+
+DistState::~DistState() {
+    if (comm) (void)ncclCommDestroy((ncclComm_t)comm);
+}
+
+static int64_t block_elems(const lsfc_plan* p) { return (int64_t)p->dist->W * p->dims[1] * p->dist->lz; }
+
+static void phase1(lsfc_plan* p, const cplx* x, bool use_nu) {
+    const DistState* d = p->dist.get();
+    pruned_xfwd(p->pads[0], p->tuning, x, use_nu ? p->nu.p : nullptr, d->S1.p, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->W, p->stream);
+}
+static void phase2(lsfc_plan* p) {
+    const DistState* d = p->dist.get();
+    const int Ly = p->pads[1], Lz = p->pads[2], m = p->dims[1], l = p->dims[2], W = d->W;
+    hipStream_t st = p->stream;
+    pruned_yfwd(Ly, p->tuning, d->R1.p, p->A2.p, p->tw[1].p, W, m, l, st);
+    pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, W, Ly,
+                  (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * Ly, (int64_t)8 * Lz, 8, st);
+    pruned_yinv(Ly, p->tuning, p->A2.p, d->R1.p, p->tw[1].p, W, m, l, st);
+}
+static void phase3(lsfc_plan* p, const cplx* x, cplx* y, double alpha, double beta) {
+    const DistState* d = p->dist.get();
+    pruned_xinv(p->pads[0], p->tuning, d->S1.p, x, y, alpha, beta, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->W, p->stream);
+}
+
+// all-to-all of equal blocks: block q of `send` goes to rank q, block q of `recv` comes from rank q
+static void exchange(lsfc_plan* p, const cplx* send, cplx* recv) {
+    DistState* d = p->dist.get();
+    const int64_t B = block_elems(p);
+    hipStream_t st = p->stream;
+    LSFC_HIP(hipMemcpyAsync(recv + d->rank * B, send + d->rank * B, (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice, st));
+    if (d->nranks == 1) return;
+    ncclComm_t comm = (ncclComm_t)d->comm;
+    LSFC_NCCL(ncclGroupStart());
+    for (int s = 1; s < d->nranks; ++s) {
+        // pairwise schedule: every GPU talks to a different peer in step s (all xGMI links busy at once)
+        const int to = (d->rank + s) % d->nranks, from = (d->rank - s + d->nranks) % d->nranks;
+        LSFC_NCCL(ncclSend(send + to * B, (size_t)B * 2, ncclDouble, to, comm, st));
+        LSFC_NCCL(ncclRecv(recv + from * B, (size_t)B * 2, ncclDouble, from, comm, st));
+    }
+    LSFC_NCCL(ncclGroupEnd());
+}
+
+void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta) {
+    DistState* d = p->dist.get();
+    LSFC_REQUIRE(!d->sim, "simulated ranks are driven through lsfc_dist_sim_apply");
+    phase1(p, x, use_nu);
+    exchange(p, d->S1.p, d->R1.p);
+    phase2(p);
+    exchange(p, d->R1.p, d->S1.p);
+    phase3(p, x, y, alpha, beta);
+}
+
+void dist_allreduce_sum(lsfc_plan* p, cplx* dev, int count) {
+    DistState* d = p->dist.get();
+    if (!d || d->sim || d->nranks == 1) return;
+    LSFC_NCCL(ncclAllReduce(dev, dev, (size_t)count * 2, ncclDouble, ncclSum, (ncclComm_t)d->comm, p->stream));
+}
+
+void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y, std::function<void(const char*, double, std::function<void()>)> add) {
+    DistState* d = p->dist.get();
+    const double N = (double)p->N, C = 16.0, om2 = p->omega * p->omega;     // N = local points
+    const int Ly = p->pads[1], Lz = p->pads[2], m = p->dims[1], l = p->dims[2], W = d->W;
+    hipStream_t st = p->stream;
+    add("xfwd", N * (C + 8) + 2 * N * C, [=] { phase1(p, x, true); });
+    add("alltoall1", 2 * N * C, [=] { exchange(p, d->S1.p, d->R1.p); });
+    add("yfwd", 6 * N * C, [=] { pruned_yfwd(Ly, p->tuning, d->R1.p, p->A2.p, p->tw[1].p, W, m, l, st); });
+    add("zfused", 16 * N * C, [=] { pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, W, Ly,
+                                   (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * Ly, (int64_t)8 * Lz, 8, st); });
+    add("yinv", 6 * N * C, [=] { pruned_yinv(Ly, p->tuning, p->A2.p, d->R1.p, p->tw[1].p, W, m, l, st); });
+    add("alltoall2", 2 * N * C, [=] { exchange(p, d->R1.p, d->S1.p); });
+    add("xinv", 4 * N * C, [=] { phase3(p, x, y, 1.0, om2); });
+}
+
+// ---------------------------------------------------------------------------
+static void make_twiddles_dist(lsfc_plan* p, int axis, int L) {
+    std::vector<cplx> tw((size_t)L);
+    for (int j = 0; j < L; ++j) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)L;
+        tw[j] = make_double2((double)cosl(a), (double)sinl(a));
+    }
+    p->tw[axis].alloc((size_t)L);
+    LSFC_HIP(hipMemcpy(p->tw[axis].p, tw.data(), (size_t)L * sizeof(cplx), hipMemcpyHostToDevice));
+}
+
+static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega, const double* nu_local,
+                             unsigned flags, int device, int rank, int nranks, const unsigned char* id, bool sim) {
+    LSFC_REQUIRE(out, "NULL argument"); *out = nullptr;
+    LSFC_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
+    LSFC_REQUIRE(n % 2 == 0 && m % 2 == 0 && l % 2 == 0, "even grid sizes only");
+    LSFC_REQUIRE(l % nranks == 0, "l = %lld is not divisible by the number of ranks %d", (long long)l, nranks);
+    for (int64_t v : { n, m, l }) LSFC_REQUIRE(pruned_length_supported(2 * v), "distributed plan needs power-of-two n, m, l in [16, 1024]");
+    LSFC_REQUIRE((2 * n / 8) % nranks == 0 && is_pow2(nranks), "number of ranks must be a power of two dividing 2n/8");
+    std::unique_ptr<lsfc_plan> p(new lsfc_plan());
+    const int lz = (int)(l / nranks);
+    // local nu: n*m*lz doubles
+    plan_common_init(p.get(), 3, n, m, lz, nu_local, omega, LSFC_QUAD_GREENGARD_VICO, flags & ~LSFC_FLAG_LITERAL_PAD, device);
+    p->dims[2] = (int)l;                            // dims are global; N stays local
+    p->N = n * m * lz;
+    for (int d = 0; d < 3; ++d) { p->pads[d] = 2 * p->dims[d]; p->crop[d] = 0; }
+    p->dist.reset(new DistState());
+    DistState* d = p->dist.get();
+    d->rank = rank; d->nranks = nranks; d->sim = sim; d->lz = lz; d->W = p->pads[0] / nranks;
+    if (!sim && nranks > 1) {
+        LSFC_REQUIRE(id, "NULL unique id");
+        ncclUniqueId uid; static_assert(sizeof(uid) == LSFC_UNIQUE_ID_BYTES, "unique id size");
+        memcpy(&uid, id, sizeof uid);
+        ncclComm_t comm;
+        LSFC_NCCL(ncclCommInitRank(&comm, nranks, uid, rank));
+        d->comm = comm;
+    }
+    // symbol: every rank evaluates the reduced symbol (elementary functions + rocFFT, ~3.5 s at 512^3) and keeps
+    // only the slab of its own x' tiles in the tiled storage order
+    DevBuf<cplx> G2;
+    symbol_gv3d_reduced(p.get(), box, G2);
+    std::vector<int> perm[3]; DevBuf<int> dperm[3];
+    for (int a = 0; a < 3; ++a) {
+        perm[a].resize((size_t)p->pads[a]);
+        pruned_perm(p->pads[a], perm[a].data());
+        dperm[a].alloc(perm[a].size());
+        LSFC_HIP(hipMemcpy(dperm[a].p, perm[a].data(), perm[a].size() * sizeof(int), hipMemcpyHostToDevice));
+        make_twiddles_dist(p.get(), a, p->pads[a]);
+    }
+    const int ntiles = d->W / 8;
+    const double scale = 1.0 / ((double)p->pads[0] * p->pads[1] * p->pads[2]);
+    p->sym.alloc((size_t)d->W * p->pads[1] * p->pads[2]);
+    pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, rank * ntiles, ntiles, scale, p->stream);
+    LSFC_HIP(hipStreamSynchronize(p->stream));
+    G2.release();
+    d->S1.alloc((size_t)p->pads[0] * m * lz);
+    d->R1.alloc((size_t)d->W * m * l);
+    p->A2.alloc((size_t)d->W * p->pads[1] * l);
+    p->pipeline = lsfc_plan::PRUNED;
+    *out = p.release();
+}
+
+} // namespace lsfc
+
 using namespace lsfc;
+
 extern "C" {
+
 int lsfc_dist_unique_id(unsigned char id[LSFC_UNIQUE_ID_BYTES]) {
-    return guarded([&] { (void)id; fail(LSFC_EINVAL, "distributed plan not built yet"); });
+    return guarded([&] {
+        LSFC_REQUIRE(id, "NULL argument");
+        ncclUniqueId uid;
+        LSFC_NCCL(ncclGetUniqueId(&uid));
+        memcpy(id, &uid, LSFC_UNIQUE_ID_BYTES);
+    });
 }
-int lsfc_dist_plan_create_gv3d(lsfc_plan** out, int64_t, int64_t, int64_t, double, double, const double*, unsigned, int, int, int,
-                               const unsigned char*) {
-    return guarded([&] { if (out) *out = nullptr; fail(LSFC_EINVAL, "distributed plan not built yet"); });
+
+int lsfc_dist_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega, const double* nu_local,
+                               unsigned flags, int device, int rank, int nranks, const unsigned char id[LSFC_UNIQUE_ID_BYTES]) {
+    return guarded([&] { create_dist_plan(out, n, m, l, box, omega, nu_local, flags, device, rank, nranks, id, false); });
 }
+
+int lsfc_dist_sim_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega, const double* nu_local,
+                                   unsigned flags, int device, int rank, int nranks) {
+    return guarded([&] { create_dist_plan(out, n, m, l, box, omega, nu_local, flags, device, rank, nranks, nullptr, true); });
 }
+
+int lsfc_dist_sim_apply(lsfc_plan** plans, int nranks, const double* const* x, double* const* y, int mode) {
+    return guarded([&] {
+        LSFC_REQUIRE(plans && x && y && nranks >= 1, "bad argument");
+        for (int r = 0; r < nranks; ++r)
+            LSFC_REQUIRE(plans[r] && plans[r]->dist && plans[r]->dist->sim && plans[r]->dist->nranks == nranks && plans[r]->dist->rank == r,
+                         "plan %d is not simulated rank %d of %d", r, r, nranks);
+        LSFC_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (apply), 1 (convolve) or 2 (convolve with nu)");
+        LSFC_HIP(hipSetDevice(plans[0]->device));
+        const int64_t B = block_elems(plans[0]);
+        auto sync_all = [&] { for (int r = 0; r < nranks; ++r) LSFC_HIP(hipStreamSynchronize(plans[r]->stream)); };
+        // host vectors: stage through each plan's staging buffers
+        std::vector<const cplx*> xd((size_t)nranks); std::vector<cplx*> yd((size_t)nranks);
+        for (int r = 0; r < nranks; ++r) {
+            lsfc_plan* p = plans[r];
+            if (p->xs.n < (size_t)p->N) { p->xs.alloc((size_t)p->N); p->ys.alloc((size_t)p->N); }
+            LSFC_HIP(hipMemcpy(p->xs.p, x[r], (size_t)p->N * sizeof(cplx), hipMemcpyHostToDevice));
+            xd[r] = p->xs.p; yd[r] = p->ys.p;
+        }
+        for (int r = 0; r < nranks; ++r) phase1(plans[r], xd[r], mode != 1);
+        sync_all();
+        for (int r = 0; r < nranks; ++r) for (int q = 0; q < nranks; ++q)        // block q of rank r -> slot r of rank q
+            LSFC_HIP(hipMemcpy(plans[q]->dist->R1.p + r * B, plans[r]->dist->S1.p + q * B, (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice));
+        for (int r = 0; r < nranks; ++r) phase2(plans[r]);
+        sync_all();
+        for (int r = 0; r < nranks; ++r) for (int q = 0; q < nranks; ++q)
+            LSFC_HIP(hipMemcpy(plans[q]->dist->S1.p + r * B, plans[r]->dist->R1.p + q * B, (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice));
+        for (int r = 0; r < nranks; ++r) {
+            lsfc_plan* p = plans[r];
+            if (mode == 0) phase3(p, xd[r], yd[r], 1.0, p->omega * p->omega); else phase3(p, xd[r], yd[r], 0.0, 1.0);
+        }
+        sync_all();
+        for (int r = 0; r < nranks; ++r) LSFC_HIP(hipMemcpy(y[r], yd[r], (size_t)plans[r]->N * sizeof(cplx), hipMemcpyDeviceToHost));
+    });
+}
+
+} // extern "C"

@@ -34,31 +34,25 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
 }
 __device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
 
-// exp(-DIR * 2*pi*i * K / R) * a for compile-time K, R in {2,4,8,16}.
+// exp(-DIR * 2*pi*i * K / R) * a for compile-time K, R in {2,4,8,16,32}.
 template <int R, int K, int DIR> struct MulW {
     __device__ __forceinline__ static cplx apply(cplx a) {
-        constexpr int idx = ((K * (16 / R)) % 16 + 16) % 16;
-        constexpr double C16[16] = { 1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
-                                     0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848,
-                                    -1.0, -0.92387953251128673848, -0.70710678118654752440, -0.38268343236508977173,
-                                     0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848 };
-        constexpr double S16[16] = { 0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
-                                     1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
-                                     0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848,
-                                    -1.0, -0.92387953251128673848, -0.70710678118654752440, -0.38268343236508977173 };
+        constexpr int idx = ((K * (32 / R)) % 32 + 32) % 32;
+        constexpr double C32[32] = { 1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254523567, 0.70710678118654757274, 0.55557023301960228867, 0.38268343236508983729, 0.19509032201612833135, 0.00000000000000006123, -0.19509032201612819257, -0.38268343236508972627, -0.55557023301960195560, -0.70710678118654746172, -0.83146961230254534669, -0.92387953251128673848, -0.98078528040323043058, -1.00000000000000000000, -0.98078528040323043058, -0.92387953251128684951, -0.83146961230254545772, -0.70710678118654768376, -0.55557023301960217765, -0.38268343236509033689, -0.19509032201612866442, -0.00000000000000018370, 0.19509032201612830359, 0.38268343236509000382, 0.55557023301960184458, 0.70710678118654735069, 0.83146961230254523567, 0.92387953251128651644, 0.98078528040323031956 };
+        constexpr double S32[32] = { 0.00000000000000000000, 0.19509032201612824808, 0.38268343236508978178, 0.55557023301960217765, 0.70710678118654746172, 0.83146961230254523567, 0.92387953251128673848, 0.98078528040323043058, 1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254545772, 0.70710678118654757274, 0.55557023301960217765, 0.38268343236508989280, 0.19509032201612860891, 0.00000000000000012246, -0.19509032201612835911, -0.38268343236508967076, -0.55557023301960195560, -0.70710678118654746172, -0.83146961230254523567, -0.92387953251128651644, -0.98078528040323031956, -1.00000000000000000000, -0.98078528040323043058, -0.92387953251128662746, -0.83146961230254545772, -0.70710678118654768376, -0.55557023301960217765, -0.38268343236509039240, -0.19509032201612871993 };
         if constexpr (idx == 0) return a;
-        else if constexpr (idx == 8) return make_double2(-a.x, -a.y);
-        else if constexpr (idx == 4) return DIR > 0 ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x);
-        else if constexpr (idx == 12) return DIR > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
-        else if constexpr (idx == 2) {
+        else if constexpr (idx == 16) return make_double2(-a.x, -a.y);
+        else if constexpr (idx == 8) return DIR > 0 ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x);
+        else if constexpr (idx == 24) return DIR > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+        else if constexpr (idx == 4) {
             constexpr double c = 0.70710678118654752440;
             return DIR > 0 ? make_double2((a.x + a.y) * c, (a.y - a.x) * c) : make_double2((a.x - a.y) * c, (a.x + a.y) * c);
-        } else if constexpr (idx == 6) {
+        } else if constexpr (idx == 12) {
             constexpr double c = 0.70710678118654752440;
             return DIR > 0 ? make_double2((a.y - a.x) * c, -(a.x + a.y) * c) : make_double2(-(a.x + a.y) * c, (a.x - a.y) * c);
         } else {
-            constexpr double wr = C16[idx];
-            constexpr double wi = (DIR > 0 ? -1.0 : 1.0) * S16[idx];
+            constexpr double wr = C32[idx];
+            constexpr double wi = (DIR > 0 ? -1.0 : 1.0) * S32[idx];
             return make_double2(fma(-a.y, wi, a.x * wr), fma(a.x, wi, a.y * wr));
         }
     }
@@ -143,6 +137,11 @@ template <int R> __device__ __forceinline__ void twiddle_powers(cplx w1, cplx (&
         w[8] = cmul(w[4], w[4]);
 #pragma unroll
         for (int k = 9; k < 16; ++k) w[k] = cmul(w[8], w[k - 8]);
+    }
+    if constexpr (R > 16) {
+        w[16] = cmul(w[8], w[8]);
+#pragma unroll
+        for (int k = 17; k < 32; ++k) w[k] = cmul(w[16], w[k - 16]);
     }
 }
 

@@ -27,7 +27,7 @@ static constexpr int XB = 8;           // x' lines per strided workgroup: 8 * 16
 template <class C, int LPW, bool SPLIT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __restrict__ out,
-            const cplx* __restrict__ tw, int64_t nlines) {
+            const cplx* __restrict__ tw, int64_t nlines, int logW) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, n = C::L / 2;
@@ -48,16 +48,21 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
     fft_forward<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
     if (valid) {
-        cplx* o = out + line * C::L;
+        // storage index s of this line goes to chunk s>>logW (one chunk per destination rank of the slab
+        // transpose; a single chunk of width L on one GPU): out[chunk][line][s & (W-1)]
+        const int64_t W = (int64_t)1 << logW;
 #pragma unroll
-        for (int e = 0; e < E; ++e) o[t + T * e] = v[e];
+        for (int e = 0; e < E; ++e) {
+            const int s = t + T * e;
+            out[(int64_t)(s >> logW) * (W * nlines) + line * W + (s & (W - 1))] = v[e];
+        }
     }
 }
 
 template <class C, int LPW, bool SPLIT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alpha, double beta,
-            const cplx* __restrict__ tw, int64_t nlines) {
+            const cplx* __restrict__ tw, int64_t nlines, int logW) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, n = C::L / 2;
@@ -65,10 +70,13 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
     const int64_t line = (int64_t)blockIdx.x * LPW + ll;
     const bool valid = line < nlines;
     const int64_t lc = valid ? line : nlines - 1;
-    const cplx* i = in + lc * C::L;
+    const int64_t W = (int64_t)1 << logW;
     cplx v[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = i[t + T * e];
+    for (int e = 0; e < E; ++e) {
+        const int s = t + T * e;
+        v[e] = in[(int64_t)(s >> logW) * (W * nlines) + lc * W + (s & (W - 1))];
+    }
     fft_inverse<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
     if (valid) {
 #pragma unroll
@@ -84,13 +92,17 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
 // A1[Lx][m][l] (natural) -> A2[XB][l][Ly][Lx/XB]
 template <class C, int LINES, bool SPLIT>
 __global__ __launch_bounds__(C::T * LINES)
-void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __restrict__ tw, int Lx, int m, int l) {
+void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, Ly = C::L;
     const int xi = threadIdx.x % LINES, t = threadIdx.x / LINES;
     const int ngrp = Lx / LINES;
-    const int g = blockIdx.x % ngrp, z = blockIdx.x / ngrp;
+    // block order: (TG x TZ) tiles of (x'-group, z), groups fastest inside a tile and across tiles, so that the
+    // workgroups in flight together touch short contiguous runs in BOTH the natural and the tiled array
+    const int within = blockIdx.x % (TG * TZ), tile = blockIdx.x / (TG * TZ);
+    const int ntg = ngrp / TG;
+    const int g = (tile % ntg) * TG + within % TG, z = (tile / ntg) * TZ + within / TG;
     const int xp = g * LINES + xi;                       // x' storage index
     const cplx* src = a1 + xp + (int64_t)Lx * m * z;
     cplx v[E];
@@ -107,13 +119,17 @@ void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __re
 
 template <class C, int LINES, bool SPLIT>
 __global__ __launch_bounds__(C::T * LINES)
-void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __restrict__ tw, int Lx, int m, int l) {
+void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, Ly = C::L;
     const int xi = threadIdx.x % LINES, t = threadIdx.x / LINES;
     const int ngrp = Lx / LINES;
-    const int g = blockIdx.x % ngrp, z = blockIdx.x / ngrp;
+    // block order: (TG x TZ) tiles of (x'-group, z), groups fastest inside a tile and across tiles, so that the
+    // workgroups in flight together touch short contiguous runs in BOTH the natural and the tiled array
+    const int within = blockIdx.x % (TG * TZ), tile = blockIdx.x / (TG * TZ);
+    const int ntg = ngrp / TG;
+    const int g = (tile % ntg) * TG + within % TG, z = (tile / ntg) * TZ + within / TG;
     const int xp = g * LINES + xi;
     const int xb = xp / XB, xq = xp % XB;
     const cplx* src = a2 + xq + (int64_t)XB * (z + (int64_t)l * ((int64_t)Ly * xb));
@@ -129,7 +145,7 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
 // In-place forward -> .* sym -> inverse along one strided axis.
 // Line (g, outer, xi): element j at data[g*dGrp + outer*dOuter + xi + dLine*j],
 // symbol entry for storage index s at sym[g*sGrp + outer*sOuter + xi + sLine*s].
-template <class C, int LINES, bool SPLIT>
+template <class C, int LINES, bool SPLIT, bool PREFETCH>
 __global__ __launch_bounds__(C::T * LINES)
 void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
               int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine) {
@@ -145,9 +161,19 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
     for (int e = 0; e < E / 2; ++e) v[e] = d[dLine * (t + T * e)];
 #pragma unroll
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
-    fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
+    if constexpr (PREFETCH) {
+        // issue the symbol loads before the forward transform: their HBM latency hides behind its butterflies
+        cplx sv[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = cmul(v[e], s[sLine * (t + T * e)]);
+        for (int e = 0; e < E; ++e) sv[e] = s[sLine * (t + T * e)];
+        fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = cmul(v[e], sv[e]);
+    } else {
+        fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = cmul(v[e], s[sLine * (t + T * e)]);
+    }
     fft_inverse<C, LL, true>(v, t, tw, smem, 0, xi);
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) d[dLine * (t + T * e)] = v[e];
@@ -168,39 +194,45 @@ template <class C> struct Tune {
     static constexpr int LINES = (C::T * XB <= 512) ? XB : 512 / C::T;
 };
 
-template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, hipStream_t st) {
+template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int logW, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = k_xfwd<C, LPW, SPLIT>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW);
 }
-template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, hipStream_t st) {
+template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int logW, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = k_xinv<C, LPW, SPLIT>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW);
 }
-template <class C, bool SPLIT> static void yfwd_t(const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
+static void ytile(const PrunedTuning& tn, int ngrp, int l, int& TG, int& TZ) {
+    TG = tn.ytile_g > 0 ? tn.ytile_g : ngrp; if (TG > ngrp) TG = ngrp; while (ngrp % TG) --TG;
+    TZ = tn.ytile_z > 0 ? tn.ytile_z : 1;    if (TZ > l) TZ = l;       while (l % TZ) --TZ;
+}
+template <class C, bool SPLIT> static void yfwd_t(const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
     constexpr int LINES = Tune<C>::LINES;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     auto k = k_yfwd<C, LINES, SPLIT>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a1, a2, tw, Lx, m, l);
+    int TG, TZ; ytile(tn, Lx / LINES, l, TG, TZ);
+    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a1, a2, tw, Lx, m, l, TG, TZ);
 }
-template <class C, bool SPLIT> static void yinv_t(const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
+template <class C, bool SPLIT> static void yinv_t(const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
     constexpr int LINES = Tune<C>::LINES;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     auto k = k_yinv<C, LINES, SPLIT>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l);
+    int TG, TZ; ytile(tn, Lx / LINES, l, TG, TZ);
+    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l, TG, TZ);
 }
-template <class C, bool SPLIT> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+template <class C, bool SPLIT, bool PREFETCH> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                                                     int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
                                                     hipStream_t st) {
     // dTile/sTile are strides per XB-tile of x'; a workgroup covers LINES of the XB lines of a tile.
@@ -208,7 +240,7 @@ template <class C, bool SPLIT> static void zfused_t(cplx* data, const cplx* sym,
     static_assert(XB % LINES == 0, "LINES must divide XB");
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = k_zfused<C, LINES, SPLIT>;
+    auto k = k_zfused<C, LINES, SPLIT, PREFETCH>;
     allow_lds(k, lds);
     if (LINES == XB) {
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / XB) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
@@ -251,33 +283,42 @@ PrunedTuning pruned_default_tuning() {
     PrunedTuning t;
     t.split_x = env_flag("LSFC_SPLIT_X", true);
     t.split_s = env_flag("LSFC_SPLIT_S", true);
+    t.sym_prefetch = env_flag("LSFC_SYM_PREFETCH", false);
+    if (const char* v = getenv("LSFC_YTILE_G")) t.ytile_g = atoi(v);
+    if (const char* v = getenv("LSFC_YTILE_Z")) t.ytile_z = atoi(v);
     return t;
 }
 
-void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, hipStream_t st) {
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, st))); }
-    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, st))); }
+static int log2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; LSFC_REQUIRE((1 << l) == v, "chunk width %d is not a power of two", v); return l; }
+
+void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, hipStream_t st) {
+    const int logW = log2_exact(W);
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, logW, st))); }
+    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, logW, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, hipStream_t st) {
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, st))); }
-    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, st))); }
+void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, hipStream_t st) {
+    const int logW = log2_exact(W);
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, logW, st))); }
+    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, logW, st))); }
     LSFC_HIP(hipGetLastError());
 }
 void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
-    if (tn.split_s) { LSFC_DISPATCH_L(L, (yfwd_t<C, true>(a1, a2, tw, Lx, m, l, st))); }
-    else            { LSFC_DISPATCH_L(L, (yfwd_t<C, false>(a1, a2, tw, Lx, m, l, st))); }
+    if (tn.split_s) { LSFC_DISPATCH_L(L, (yfwd_t<C, true>(tn, a1, a2, tw, Lx, m, l, st))); }
+    else            { LSFC_DISPATCH_L(L, (yfwd_t<C, false>(tn, a1, a2, tw, Lx, m, l, st))); }
     LSFC_HIP(hipGetLastError());
 }
 void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
-    if (tn.split_s) { LSFC_DISPATCH_L(L, (yinv_t<C, true>(a2, a1, tw, Lx, m, l, st))); }
-    else            { LSFC_DISPATCH_L(L, (yinv_t<C, false>(a2, a1, tw, Lx, m, l, st))); }
+    if (tn.split_s) { LSFC_DISPATCH_L(L, (yinv_t<C, true>(tn, a2, a1, tw, Lx, m, l, st))); }
+    else            { LSFC_DISPATCH_L(L, (yinv_t<C, false>(tn, a2, a1, tw, Lx, m, l, st))); }
     LSFC_HIP(hipGetLastError());
 }
 void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, hipStream_t st) {
-    if (tn.split_s) { LSFC_DISPATCH_L(L, (zfused_t<C, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, st))); }
-    else            { LSFC_DISPATCH_L(L, (zfused_t<C, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, st))); }
+#define LSFC_ZF(SP, PF) LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, st)))
+    if (tn.split_s) { if (tn.sym_prefetch) { LSFC_ZF(true, true); } else { LSFC_ZF(true, false); } }
+    else            { if (tn.sym_prefetch) { LSFC_ZF(false, true); } else { LSFC_ZF(false, false); } }
+#undef LSFC_ZF
     LSFC_HIP(hipGetLastError());
 }
 

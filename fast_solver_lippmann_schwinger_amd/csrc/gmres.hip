@@ -85,6 +85,10 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
     GmresWorkspace* w = workspace(p, restart, o.precond != nullptr);
     hipStream_t st = p->stream;
     auto Vcol = [&](int j) { return w->V.p + (size_t)j * (size_t)N; };
+    // slab-distributed plan: every inner product / squared norm is completed by an all-reduce over the ranks
+    const bool multi = p->dist && !p->dist->sim && p->dist->nranks > 1;
+    auto finish_dot = [&](cplx* s, int count) { if (multi) dist_allreduce_sum(p, s, count); };
+    auto finish_nrm = [&](cplx* s) { if (multi) { dist_allreduce_sum(p, s, 1); blas_sqrt_dev(s, st); } };
 
     auto precondition = [&](cplx* v) {
         if (!o.precond) return;
@@ -105,7 +109,8 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
         if (skip_mv) LSFC_HIP(hipMemcpyAsync(v0, b, (size_t)N * sizeof(cplx), hipMemcpyDeviceToDevice, st));
         else { plan_apply_dev(p, x, w->ax.p); blas_sub(v0, b, w->ax.p, N, st); }
         precondition(v0);
-        blas_nrm2(v0, w->partial.p, w->hdev.p, N, st);
+        blas_nrm2(v0, w->partial.p, w->hdev.p, N, st, multi);
+        finish_nrm(w->hdev.p);
         blas_scale_inv_dev(v0, w->hdev.p, N, st);
         fetch_h(1);
         return w->hpin[0].x;
@@ -131,8 +136,11 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
         if (o.orth == LSFC_ORTH_MGS) {
             // h_i = <V_i, w>; w -= h_i V_i, each sweep fused with the next inner product (norm after the last)
             blas_dot(Vcol(0), wv, w->partial.p, w->hdev.p, N, st);
-            for (int i = 0; i < k; ++i)
-                blas_axpy_dot(wv, Vcol(i), w->hdev.p + i, (i + 1 < k) ? Vcol(i + 1) : nullptr, w->partial.p, w->hdev.p + i + 1, N, st);
+            finish_dot(w->hdev.p, 1);
+            for (int i = 0; i < k; ++i) {
+                blas_axpy_dot(wv, Vcol(i), w->hdev.p + i, (i + 1 < k) ? Vcol(i + 1) : nullptr, w->partial.p, w->hdev.p + i + 1, N, st, multi);
+                if (i + 1 < k) finish_dot(w->hdev.p + i + 1, 1); else finish_nrm(w->hdev.p + i + 1);
+            }
             blas_scale_inv_dev(wv, w->hdev.p + k, N, st);
             fetch_h(k + 1);
             nrm = w->hpin[k].x;
@@ -141,11 +149,13 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
                 const int kc = std::min(64, k - j0);
                 blas_multidot(Vcol(j0), N, kc, wv, w->partial.p, w->hdev.p + j0, N, st);
             }
+            finish_dot(w->hdev.p, k);
             for (int j0 = 0; j0 < k; j0 += 64) {
                 const int kc = std::min(64, k - j0);
                 blas_gemv_acc(wv, Vcol(j0), N, kc, w->hdev.p + j0, -1.0, N, st);
             }
-            blas_nrm2(wv, w->partial.p, w->hdev.p + k, N, st);
+            blas_nrm2(wv, w->partial.p, w->hdev.p + k, N, st, multi);
+            finish_nrm(w->hdev.p + k);
             fetch_h(k + 1);
             nrm = w->hpin[k].x;
             if (o.orth == LSFC_ORTH_DGKS) {
@@ -157,11 +167,13 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
                         const int kc = std::min(64, k - j0);
                         blas_multidot(Vcol(j0), N, kc, wv, w->partial.p, w->hdev.p + j0, N, st);
                     }
+                    finish_dot(w->hdev.p, k);
                     for (int j0 = 0; j0 < k; j0 += 64) {
                         const int kc = std::min(64, k - j0);
                         blas_gemv_acc(wv, Vcol(j0), N, kc, w->hdev.p + j0, -1.0, N, st);
                     }
-                    blas_nrm2(wv, w->partial.p, w->hdev.p + k, N, st);
+                    blas_nrm2(wv, w->partial.p, w->hdev.p + k, N, st, multi);
+                    finish_nrm(w->hdev.p + k);
                     fetch_h(k + 1);
                     for (int i = 0; i < k; ++i) { w->hpin[i].x += h1[i].x; w->hpin[i].y += h1[i].y; }
                     nrm = w->hpin[k].x;

@@ -146,7 +146,7 @@ void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
             make_twiddles(p, d, p->pads[d]);
         }
         p->sym.alloc((size_t)total);
-        pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, scale, p->stream);
+        pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, 0, p->pads[0] / 8, scale, p->stream);
         LSFC_HIP(hipStreamSynchronize(p->stream));
         G2.release();
         p->A1.alloc((size_t)p->pads[0] * p->dims[1] * p->dims[2]);
@@ -196,11 +196,12 @@ void plan_finish_reduce(lsfc_plan* p, DevBuf<cplx>& Gd, const int lit[3], bool c
 void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta) {
     const double* nu = use_nu ? p->nu.p : nullptr;
     hipStream_t st = p->stream;
+    if (p->dist) { dist_convolve_dev(p, x, y, use_nu, alpha, beta); return; }
     if (p->pipeline == lsfc_plan::PRUNED) {
         const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
         const int m = p->dims[1], l = p->dims[2];
         const int64_t nlines = (int64_t)m * l;
-        pruned_xfwd(Lx, p->tuning, x, nu, p->A1.p, p->tw[0].p, nlines, st);
+        pruned_xfwd(Lx, p->tuning, x, nu, p->A1.p, p->tw[0].p, nlines, Lx, st);
         if (p->ndim == 3) {
             pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, st);
             pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
@@ -209,7 +210,7 @@ void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
         } else {
             pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, Lx, 8, 0, Lx, st);
         }
-        pruned_xinv(Lx, p->tuning, p->A1.p, x, y, alpha, beta, p->tw[0].p, nlines, st);
+        pruned_xinv(Lx, p->tuning, p->A1.p, x, y, alpha, beta, p->tw[0].p, nlines, Lx, st);
     } else {
         const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
         pw_embed(x, nu, p->W.p, p->dims, p->pads, st);
@@ -431,6 +432,19 @@ int lsfc_plan_synchronize(lsfc_plan* plan) {
     return guarded([&] { LSFC_REQUIRE(plan, "NULL plan"); LSFC_HIP(hipSetDevice(plan->device)); LSFC_HIP(hipStreamSynchronize(plan->stream)); });
 }
 
+int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan && key, "NULL argument");
+        const std::string k(key);
+        if (k == "split_x") plan->tuning.split_x = value != 0;
+        else if (k == "split_s") plan->tuning.split_s = value != 0;
+        else if (k == "sym_prefetch") plan->tuning.sym_prefetch = value != 0;
+        else if (k == "ytile_g") plan->tuning.ytile_g = value;
+        else if (k == "ytile_z") plan->tuning.ytile_z = value;
+        else fail(LSFC_EINVAL, "unknown tuning key '%s'", key);
+    });
+}
+
 int lsfc_time_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int reps, double* ms_total) {
     return guarded([&] {
         LSFC_REQUIRE(plan && x_dev && y_dev && ms_total && reps >= 1, "bad argument");
@@ -453,17 +467,23 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
         LSFC_REQUIRE(plan && x_dev && y_dev && names && ms && bytes && nstages && reps >= 1, "bad argument");
         LSFC_HIP(hipSetDevice(plan->device));
         lsfc_plan* p = plan;
+        LSFC_REQUIRE(!p->dist || !p->dist->sim, "profile_apply: not available for simulated ranks");
         const cplx* x = (const cplx*)x_dev; cplx* y = (cplx*)y_dev;
         hipStream_t st = p->stream;
         const double N = (double)p->N, C = 16.0;
         struct Stage { const char* name; double bytes; std::function<void()> run; };
         std::vector<Stage> stages;
+        auto stages_add_fn = [](std::vector<Stage>& v) {
+            return [&v](const char* name, double bytes, std::function<void()> run) { v.push_back({name, bytes, std::move(run)}); };
+        };
         const double om2 = p->omega * p->omega;
-        if (p->pipeline == lsfc_plan::PRUNED) {
+        if (p->dist) {
+            dist_profile_stages(p, x, y, stages_add_fn(stages));
+        } else if (p->pipeline == lsfc_plan::PRUNED) {
             const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
             const int m = p->dims[1], l = p->dims[2];
             const int64_t nlines = (int64_t)m * l;
-            stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, [=] { pruned_xfwd(Lx, p->tuning, x, p->nu.p, p->A1.p, p->tw[0].p, nlines, st); }});
+            stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, [=] { pruned_xfwd(Lx, p->tuning, x, p->nu.p, p->A1.p, p->tw[0].p, nlines, Lx, st); }});
             if (p->ndim == 3) {
                 stages.push_back({"yfwd", (2 + 4) * N * C, [=] { pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, st); }});
                 stages.push_back({"zfused", (4 + 8 + 4) * N * C, [=] { pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
@@ -472,7 +492,7 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
             } else {
                 stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, Lx, 8, 0, Lx, st); }});
             }
-            stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, st); }});
+            stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, Lx, st); }});
         } else {
             const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
             const double P = (double)total;

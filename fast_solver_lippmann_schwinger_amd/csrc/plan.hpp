@@ -3,6 +3,7 @@
 #include "common.hpp"
 #include "pruned.hpp"
 #include <rocfft/rocfft.h>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -43,10 +44,12 @@ struct GmresWorkspace {
 // slab-distributed state (dist.hip)
 struct DistState {
     int rank = 0, nranks = 1;
+    bool sim = false;        // simulated ranks in one process (tests): exchanges done by lsfc_dist_sim_apply
     void* comm = nullptr;    // ncclComm_t
-    int lz = 0;              // local z planes
-    int xw = 0;              // local width in x' after the transpose (Lx / nranks)
-    DevBuf<cplx> sendbuf, recvbuf;
+    int lz = 0;              // local z planes (l / nranks)
+    int W = 0;               // x' storage indices owned after the transpose (Lx / nranks)
+    DevBuf<cplx> S1;         // [nranks][W][m][lz]: xfwd output packed per destination rank / xinv input
+    DevBuf<cplx> R1;         // [W][m][l]: natural layout on the owned x' range (concatenation of received blocks)
     ~DistState();
 };
 
@@ -109,6 +112,12 @@ void plan_common_init(lsfc_plan* p, int ndim, int64_t n, int64_t m, int64_t l, c
 void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2);                  // -> (2n,2m,2l) FFT order, unscaled
 void symbol_gv2d_literal(lsfc_plan* p, double box, DevBuf<cplx>& G, int lit[3]);       // -> (4n,4m) centred
 void symbol_trap2d_literal(lsfc_plan* p, double x0, double y0, double h, cplx d0, DevBuf<cplx>& G); // -> fft(Ge), (2n-1,2m-1)
+
+// slab-distributed operator (dist.hip)
+void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta);
+void dist_allreduce_sum(lsfc_plan* p, cplx* dev, int count);           // no-op unless a real multi-rank plan
+void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y,
+                         std::function<void(const char*, double, std::function<void()>)> add);
 
 // GMRES (gmres.hip)
 void gmres_run(lsfc_plan* p, cplx* x_dev, const cplx* b_dev, const lsfc_gmres_opts* opts, double* resnorm, int64_t cap,

@@ -99,14 +99,14 @@ __global__ void k_wrap_crop(const cplx* __restrict__ src, cplx* __restrict__ dst
 // Natural FFT-order symbol G2[Lx][Ly][Lz] -> storage-order, tile-interleaved layout of the
 // pruned pipeline.  3D: out[xi + 8*(sz + Lz*(sy + Ly*xb))];  2D (Lz==1): out[sx + Lx*sy].
 __global__ void k_permute_symbol(const cplx* __restrict__ G2, cplx* __restrict__ out, const int* __restrict__ px,
-                                 const int* __restrict__ py, const int* __restrict__ pz, int Lx, int Ly, int Lz, double scale) {
-    const int64_t total = (int64_t)Lx * Ly * Lz;
+                                 const int* __restrict__ py, const int* __restrict__ pz, int Lx, int Ly, int Lz, int xb0, int ntiles, double scale) {
+    const int64_t total = (Lz > 1) ? (int64_t)8 * Lz * Ly * ntiles : (int64_t)Lx * Ly;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         int sx, sy, sz;
         if (Lz > 1) {
             const int xi = (int)(idx % 8); int64_t r = idx / 8;
             sz = (int)(r % Lz); r /= Lz; sy = (int)(r % Ly); const int xb = (int)(r / Ly);
-            sx = xb * 8 + xi;
+            sx = (xb0 + xb) * 8 + xi;
         } else { sx = (int)(idx % Lx); sy = (int)(idx / Lx); sz = 0; }
         const int kx = px[sx], ky = py[sy], kz = (Lz > 1) ? pz[sz] : 0;
         const cplx v = G2[kx + (int64_t)Lx * (ky + (int64_t)Ly * kz)];
@@ -130,9 +130,9 @@ void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], do
     hipLaunchKernelGGL(k_wrap_crop, dim3(grid_for(total)), dim3(256), 0, st, src, dst, p[0], p[1], p[2], q[0], q[1], q[2], scale);
     LSFC_HIP(hipGetLastError());
 }
-void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* py, const int* pz, const int L[3], double scale, hipStream_t st) {
-    const int64_t total = (int64_t)L[0] * L[1] * L[2];
-    hipLaunchKernelGGL(k_permute_symbol, dim3(grid_for(total)), dim3(256), 0, st, G2, out, px, py, pz, L[0], L[1], L[2], scale);
+void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* py, const int* pz, const int L[3], int xb0, int ntiles, double scale, hipStream_t st) {
+    const int64_t total = (L[2] > 1) ? (int64_t)8 * L[2] * L[1] * ntiles : (int64_t)L[0] * L[1];
+    hipLaunchKernelGGL(k_permute_symbol, dim3(grid_for(total)), dim3(256), 0, st, G2, out, px, py, pz, L[0], L[1], L[2], xb0, ntiles, scale);
     LSFC_HIP(hipGetLastError());
 }
 void pw_scale(cplx* a, double s, int64_t total, hipStream_t st) {
@@ -269,14 +269,19 @@ void blas_dot(const cplx* a, const cplx* b, cplx* partial, cplx* out, int64_t n,
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, 0);
     LSFC_HIP(hipGetLastError());
 }
-void blas_nrm2(const cplx* a, cplx* partial, cplx* out, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(k_dot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, a, a, partial, n);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, 1);
+__global__ void k_sqrt_dev(cplx* s) { if (threadIdx.x == 0) *s = make_double2(sqrt(s->x), 0.0); }
+void blas_sqrt_dev(cplx* s, hipStream_t st) {
+    hipLaunchKernelGGL(k_sqrt_dev, dim3(1), dim3(64), 0, st, s);
     LSFC_HIP(hipGetLastError());
 }
-void blas_axpy_dot(cplx* w, const cplx* v, const cplx* h, const cplx* vnext, cplx* partial, cplx* out, int64_t n, hipStream_t st) {
+void blas_nrm2(const cplx* a, cplx* partial, cplx* out, int64_t n, hipStream_t st, bool defer_sqrt) {
+    hipLaunchKernelGGL(k_dot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, a, a, partial, n);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, defer_sqrt ? 0 : 1);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_axpy_dot(cplx* w, const cplx* v, const cplx* h, const cplx* vnext, cplx* partial, cplx* out, int64_t n, hipStream_t st, bool defer_sqrt) {
     hipLaunchKernelGGL(k_axpy_dot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, w, v, h, vnext, partial, n);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, vnext ? 0 : 1);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, (vnext || defer_sqrt) ? 0 : 1);
     LSFC_HIP(hipGetLastError());
 }
 void blas_multidot(const cplx* V, int64_t ldv, int k, const cplx* w, cplx* partial, cplx* out, int64_t n, hipStream_t st) {

@@ -12,15 +12,18 @@ void pw_crop_axpy(const cplx* W, const cplx* x, cplx* y, double alpha, double be
 // symbol preparation
 void pw_roll_scale(const cplx* src, cplx* dst, const int p[3], const int s[3], double scale, hipStream_t);
 void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], double scale, hipStream_t);
-void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* py, const int* pz, const int L[3], double scale, hipStream_t);
+// 3D: tiles [xb0, xb0+ntiles) of the x' axis only (the symbol slab of one rank); 2D: whole symbol
+void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* py, const int* pz, const int L[3], int xb0, int ntiles, double scale, hipStream_t);
 void pw_scale(cplx* a, double s, int64_t total, hipStream_t);
 
 // GMRES BLAS-1 (results land in device scalars; `partial` is scratch of blas_partial_count() entries)
 int  blas_partial_count();
 void blas_dot(const cplx* a, const cplx* b, cplx* partial, cplx* out, int64_t n, hipStream_t);          // out = a' * b
-void blas_nrm2(const cplx* a, cplx* partial, cplx* out, int64_t n, hipStream_t);                          // out.x = ||a||
+// defer_sqrt: leave the sum of squares (to be all-reduced across ranks, then blas_sqrt_dev)
+void blas_nrm2(const cplx* a, cplx* partial, cplx* out, int64_t n, hipStream_t, bool defer_sqrt = false);  // out.x = ||a||
+void blas_sqrt_dev(cplx* s, hipStream_t);
 // w -= h[0]*v ; then out = vnext' * w (vnext != NULL) or out.x = ||w|| (vnext == NULL)
-void blas_axpy_dot(cplx* w, const cplx* v, const cplx* h, const cplx* vnext, cplx* partial, cplx* out, int64_t n, hipStream_t);
+void blas_axpy_dot(cplx* w, const cplx* v, const cplx* h, const cplx* vnext, cplx* partial, cplx* out, int64_t n, hipStream_t, bool defer_sqrt = false);
 void blas_multidot(const cplx* V, int64_t ldv, int k, const cplx* w, cplx* partial, cplx* out, int64_t n, hipStream_t); // out[j] = V_j' * w
 void blas_gemv_acc(cplx* y, const cplx* V, int64_t ldv, int k, const cplx* c, double sign, int64_t n, hipStream_t);      // y += sign * V c
 void blas_sub(cplx* y, const cplx* a, const cplx* b, int64_t n, hipStream_t);

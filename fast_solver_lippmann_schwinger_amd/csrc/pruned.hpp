@@ -7,16 +7,20 @@ namespace lsfc {
 struct PrunedTuning {
     bool split_x = true;   // contiguous (x) passes: exchange re/im separately (half the LDS, twice the barriers)
     bool split_s = true;   // strided (y, z) passes
+    bool sym_prefetch = false;  // z pass: load the symbol before the forward transform (64 more VGPRs at E=16)
+    int ytile_g = 0, ytile_z = 0;   // y passes: block-order tile (x'-groups x z planes); 0 = all groups x 1 plane
 };
 
 bool pruned_length_supported(int64_t L);
+// W = chunk width of the x'-storage axis in the xfwd output / xinv input: out[s / W][line][s % W] (W = L on one GPU;
+// W = L / nranks packs the slab transpose for free).
 // freq_of_storage[s] = frequency index held at storage index s after the forward pass of length L
 void pruned_perm(int L, int* freq_of_storage);
 PrunedTuning pruned_default_tuning();
 
-void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, hipStream_t);
+void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, hipStream_t);
 void pruned_xinv(int L, const PrunedTuning&, const cplx* in, const cplx* xorig, cplx* y, double alpha, double beta,
-                 const cplx* tw, int64_t nlines, hipStream_t);
+                 const cplx* tw, int64_t nlines, int W, hipStream_t);
 void pruned_yfwd(int L, const PrunedTuning&, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t);
 void pruned_yinv(int L, const PrunedTuning&, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t);
 void pruned_zfused(int L, const PrunedTuning&, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,

@@ -1,0 +1,100 @@
+"""Slab-distributed 3D operator: one process per GPU, z-slabs, RCCL all-to-all over xGMI
+(csrc/dist.hip).  The reference has no distributed mode; this is the multi-GPU
+form of `buildFastConvolution3D` + `*` (src/FastConvolution3D.jl:31-101).
+
+torch.distributed is used only as plumbing: to ship the 128-byte RCCL unique id from rank 0 to
+the other ranks.  The data-path collectives are issued by the HIP library itself."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .operators import FastM3D
+
+
+def slab_range(l, rank, nranks):
+    """z planes [lo, hi) owned by `rank` (the library requires nranks | l)."""
+    if l % nranks:
+        raise ValueError(f"l = {l} is not divisible by the number of ranks {nranks}")
+    lz = l // nranks
+    return rank * lz, (rank + 1) * lz
+
+
+def exchange_unique_id(rank, nranks, group=None):
+    """Rank 0 creates the RCCL unique id; everyone receives it through torch.distributed."""
+    import torch
+    import torch.distributed as dist
+    buf = (C.c_ubyte * L.LSFC_UNIQUE_ID_BYTES)()
+    if rank == 0:
+        L.check(L.load().lsfc_dist_unique_id(buf))
+    if nranks > 1:
+        backend = dist.get_backend(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0, group=group)
+        buf = (C.c_ubyte * L.LSFC_UNIQUE_ID_BYTES)(*t.cpu().tolist())
+    return buf
+
+
+def build_distributed_3d(n, h, k, nu_local, rank, nranks, device, m=None, l=None, flags=0, group=None):
+    """Distributed `buildFastConvolution3D` on the half-open grid x = x0 + h*(0..n-1): this rank passes the contrast
+    on its own z planes (flat, x fastest).  Returns a FastM3D whose vectors are the local slabs."""
+    m = n if m is None else m
+    l = n if l is None else l
+    lo, hi = slab_range(l, rank, nranks)
+    nuv = np.ascontiguousarray(nu_local, dtype=np.float64).reshape(-1)
+    if nuv.size != n * m * (hi - lo):
+        raise ValueError("DimensionMismatch: nu_local")
+    box = n * h                                   # |x[end] - x[1]| + h
+    uid = exchange_unique_id(rank, nranks, group)
+    plan = C.c_void_p()
+    L.check(L.load().lsfc_dist_plan_create_gv3d(C.byref(plan), n, m, l, float(box), float(k), nuv.ctypes.data_as(C.c_void_p),
+                                                flags, device, rank, nranks, uid))
+    return FastM3D(None, nuv, 4 * n, 4 * m, 4 * l, n, m, l, k, _plan=plan)
+
+
+class SimulatedRanks:
+    """`nranks` logical ranks on ONE device (lsfc_dist_sim_*): the test double of the multi-GPU operator.  Same
+    kernels, layouts and symbol slabs; the two slab exchanges are device-to-device copies instead of RCCL."""
+
+    def __init__(self, n, m, l, h, k, nu, nranks, device=0, flags=0):
+        self.n, self.m, self.l, self.nranks = n, m, l, nranks
+        nu = np.ascontiguousarray(nu, dtype=np.float64).reshape(-1)
+        self.plans = (C.c_void_p * nranks)()
+        self.bounds = [slab_range(l, r, nranks) for r in range(nranks)]
+        for r, (lo, hi) in enumerate(self.bounds):
+            loc = np.ascontiguousarray(nu[n * m * lo:n * m * hi])
+            plan = C.c_void_p()
+            L.check(L.load().lsfc_dist_sim_plan_create_gv3d(C.byref(plan), n, m, l, float(n * h), float(k),
+                                                            loc.ctypes.data_as(C.c_void_p), flags, device, r, nranks))
+            self.plans[r] = plan
+
+    def _run(self, b, mode):
+        n, m = self.n, self.m
+        b = np.ascontiguousarray(b, dtype=np.complex128)
+        xs = [np.ascontiguousarray(b[n * m * lo:n * m * hi]) for lo, hi in self.bounds]
+        ys = [np.empty_like(x) for x in xs]
+        xp = (C.c_void_p * self.nranks)(*[x.ctypes.data for x in xs])
+        yp = (C.c_void_p * self.nranks)(*[y.ctypes.data for y in ys])
+        L.check(L.load().lsfc_dist_sim_apply(self.plans, self.nranks, xp, yp, mode))
+        return np.concatenate(ys)
+
+    def apply(self, b):
+        return self._run(b, 0)
+
+    def convolve(self, b, apply_nu=False):
+        return self._run(b, 2 if apply_nu else 1)
+
+    def close(self):
+        for r in range(self.nranks):
+            if self.plans[r]:
+                L.load().lsfc_plan_destroy(self.plans[r])
+                self.plans[r] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

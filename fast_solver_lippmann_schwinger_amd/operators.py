@@ -124,6 +124,11 @@ class _Operator:
         L.check(L.load().lsfc_plan_get_symbol(self._plan, out.ctypes.data_as(C.c_void_p), cnt.value, C.byref(cnt)))
         return out
 
+    def set_tuning(self, **knobs):
+        """Benchmark knobs of the pruned pipeline (results never depend on them)."""
+        for key, value in knobs.items():
+            L.check(L.load().lsfc_plan_set_tuning(self._plan, key.encode(), int(value)))
+
     def synchronize(self):
         L.check(L.load().lsfc_plan_synchronize(self._plan))
 

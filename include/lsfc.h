@@ -178,6 +178,10 @@ int lsfc_time_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int rep
 int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int reps,
                        int max_stages, const char** names, double* ms, double* bytes, int* nstages);
 
+/* Tuning knobs of the pruned pipeline (benchmarks / autotuning): "split_x", "split_s", "sym_prefetch",
+ * "ytile_g", "ytile_z".  Results never depend on them. */
+int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value);
+
 /* ---- device memory helpers for hosts without a HIP binding ---------------- */
 int lsfc_device_count(int* count);
 int lsfc_malloc(void** dptr, size_t bytes, int device);
@@ -198,6 +202,14 @@ int lsfc_dist_unique_id(unsigned char id[LSFC_UNIQUE_ID_BYTES]);
 int lsfc_dist_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega,
                                const double* nu_local, unsigned flags, int device,
                                int rank, int nranks, const unsigned char id[LSFC_UNIQUE_ID_BYTES]);
+
+/* Testing aid for hosts with fewer GPUs than ranks: `nranks` logical ranks as separate plans on ONE device, driven
+ * in lock step by lsfc_dist_sim_apply, which performs the two slab exchanges with device-to-device copies instead
+ * of RCCL.  Exercises exactly the kernels, layouts and symbol slabs of the multi-GPU path.  x[r], y[r]: host
+ * vectors of the local size of rank r.  mode: 0 apply, 1 convolve, 2 convolve with nu. */
+int lsfc_dist_sim_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega,
+                                   const double* nu_local, unsigned flags, int device, int rank, int nranks);
+int lsfc_dist_sim_apply(lsfc_plan** plans, int nranks, const double* const* x, double* const* y, int mode);
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* lsfc_last_error(void);

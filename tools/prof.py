@@ -1,5 +1,5 @@
 """Developer harness: time the device apply stage by stage under tuning variants.
-usage: python tools/prof.py [n ...]   (3D cubes; env LSFC_* variants are swept in-process)"""
+usage: python tools/prof.py [n ...]   (3D cubes)"""
 import os
 import sys
 import time
@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fast_solver_lippmann_schwinger_amd as lsfc  # noqa: E402
 
 PEAK = 8.0e12
+BASE = dict(split_x=1, split_s=1, sym_prefetch=0, ytile_g=0, ytile_z=0)
 
 
 def run(n, variants, reps=5):
@@ -19,30 +20,40 @@ def run(n, variants, reps=5):
     N = n ** 3
     rng = np.random.default_rng(0)
     nu = rng.uniform(-0.3, 0.3, N)
-    for name, env in variants:
-        for k_, v in env.items():
-            os.environ[k_] = v
-        t0 = time.time()
-        M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, 1.0 / h, nu)
-        t_plan = time.time() - t0
-        xb = torch.randn(N, dtype=torch.complex128, device="cuda")
-        yb = torch.empty_like(xb)
+    t0 = time.time()
+    M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, 1.0 / h, nu)
+    print(f"n={n} plan {time.time()-t0:.1f}s pipeline={M.pipeline}", flush=True)
+    xb = torch.randn(N, dtype=torch.complex128, device="cuda")
+    yb = torch.empty_like(xb)
+    ref = None
+    for name, knobs in variants:
+        kn = dict(BASE); kn.update(knobs)
+        M.set_tuning(**kn)
         lsfc.time_apply(M, xb, yb, 2)
-        ms = lsfc.time_apply(M, xb, yb, reps) / reps
+        ms = min(lsfc.time_apply(M, xb, yb, reps) / reps for _ in range(3))
+        if ref is None:
+            ref = yb.clone()
+        same = bool(torch.equal(ref, yb))
         frac = 568.0 * N / (ms * 1e-3) / PEAK
-        print(f"n={n} {name:28s} pipeline={M.pipeline} plan={t_plan:.1f}s apply={ms:.3f} ms  {1e3/ms:.1f} applies/s  alg-roofline={frac*100:.1f}%", flush=True)
-        for st, sms, sb in lsfc.profile_apply(M, xb, yb, reps):
-            print(f"      {st:10s} {sms:8.3f} ms  {sb/1e9:7.2f} GB  {sb/(sms*1e-3)/1e12:6.2f} TB/s", flush=True)
-        M.close()
-        del xb, yb
-        torch.cuda.empty_cache()
+        st = lsfc.profile_apply(M, xb, yb, reps)
+        detail = " ".join(f"{s}={t:.3f}({b/(t*1e-3)/1e12:.2f})" for s, t, b in st)
+        print(f"n={n} {name:34s} apply={ms:7.3f} ms {1e3/ms:7.1f}/s roof={frac*100:5.1f}% same={same} | {detail}", flush=True)
+    M.close()
 
 
 if __name__ == "__main__":
-    ns = [int(a) for a in sys.argv[1:]] or [256]
-    variants = [("split_x=1 split_s=1", {"LSFC_SPLIT_X": "1", "LSFC_SPLIT_S": "1"}),
-                ("split_x=0 split_s=1", {"LSFC_SPLIT_X": "0", "LSFC_SPLIT_S": "1"}),
-                ("split_x=1 split_s=0", {"LSFC_SPLIT_X": "1", "LSFC_SPLIT_S": "0"}),
-                ("split_x=0 split_s=0", {"LSFC_SPLIT_X": "0", "LSFC_SPLIT_S": "0"})]
+    ns = [int(a) for a in sys.argv[1:]] or [512]
+    variants = [("base", {}),
+                ("sym_prefetch", dict(sym_prefetch=1)),
+                ("split_s=0", dict(split_s=0)),
+                ("split_s=0 sym_prefetch", dict(split_s=0, sym_prefetch=1)),
+                ("ytile 16x16", dict(ytile_g=16, ytile_z=16)),
+                ("ytile 8x32", dict(ytile_g=8, ytile_z=32)),
+                ("ytile 32x8", dict(ytile_g=32, ytile_z=8)),
+                ("ytile 4x64", dict(ytile_g=4, ytile_z=64)),
+                ("ytile 1x256", dict(ytile_g=1, ytile_z=256)),
+                ("ytile 64x4", dict(ytile_g=64, ytile_z=4)),
+                ("ytile 2x128", dict(ytile_g=2, ytile_z=128)),
+                ("split_x=0", dict(split_x=0))]
     for n in ns:
         run(n, variants)
