@@ -197,17 +197,18 @@ __device__ __forceinline__ void lds_read(cplx (&v)[C::E], int t, const char* sme
 }
 
 #ifndef LSFC_FFT_HOST_EMULATION
+template <class LL> __device__ __forceinline__ void lds_barrier() { LSFC_BARRIER(); }
 // Move every element from its stage-SA owner to its stage-SB owner through LDS.
 template <class C, int SA, int SB, class LL>
 __device__ __forceinline__ void exchange(cplx (&v)[C::E], int t, char* smem, int off, int xi) {
     if constexpr (LL::SPLIT) {
-        lds_write<C, SA, LL, 0>(v, t, smem, off, xi); LSFC_BARRIER();
-        lds_read<C, SB, LL, 0>(v, t, smem, off, xi);  LSFC_BARRIER();
-        lds_write<C, SA, LL, 1>(v, t, smem, off, xi); LSFC_BARRIER();
-        lds_read<C, SB, LL, 1>(v, t, smem, off, xi);  LSFC_BARRIER();
+        lds_write<C, SA, LL, 0>(v, t, smem, off, xi); lds_barrier<LL>();
+        lds_read<C, SB, LL, 0>(v, t, smem, off, xi);  lds_barrier<LL>();
+        lds_write<C, SA, LL, 1>(v, t, smem, off, xi); lds_barrier<LL>();
+        lds_read<C, SB, LL, 1>(v, t, smem, off, xi);  lds_barrier<LL>();
     } else {
-        lds_write<C, SA, LL, 2>(v, t, smem, off, xi); LSFC_BARRIER();
-        lds_read<C, SB, LL, 2>(v, t, smem, off, xi);  LSFC_BARRIER();
+        lds_write<C, SA, LL, 2>(v, t, smem, off, xi); lds_barrier<LL>();
+        lds_read<C, SB, LL, 2>(v, t, smem, off, xi);  lds_barrier<LL>();
     }
 }
 #endif

@@ -145,6 +145,10 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
 // In-place forward -> .* sym -> inverse along one strided axis.
 // Line (g, outer, xi): element j at data[g*dGrp + outer*dOuter + xi + dLine*j],
 // symbol entry for storage index s at sym[g*sGrp + outer*sOuter + xi + sLine*s].
+// PREFETCH: the symbol loads are issued before the forward transform, so their HBM latency hides behind its
+// butterflies (+E complex registers; pays at E = 16 where the kernel runs at 2 waves/SIMD either way).
+// Tried and dropped (profiles/r01_experiment_*.log): LDS-only exchange barriers, non-temporal accesses, and a
+// persistent software-pipelined form of all five kernels (register pressure and spills cost more than the overlap won).
 template <class C, int LINES, bool SPLIT, bool PREFETCH>
 __global__ __launch_bounds__(C::T * LINES)
 void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
@@ -210,9 +214,12 @@ template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo
     allow_lds(k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW);
 }
-static void ytile(const PrunedTuning& tn, int ngrp, int l, int& TG, int& TZ) {
-    TG = tn.ytile_g > 0 ? tn.ytile_g : ngrp; if (TG > ngrp) TG = ngrp; while (ngrp % TG) --TG;
-    TZ = tn.ytile_z > 0 ? tn.ytile_z : 1;    if (TZ > l) TZ = l;       while (l % TZ) --TZ;
+static void ytile(const PrunedTuning& tn, int L, int ngrp, int l, int& TG, int& TZ) {
+    // auto (0): all groups x 1 plane, except at L >= 1024 where 32 groups x 8 planes keeps the 128-B chunks that the
+    // workgroups in flight touch together within a few DRAM pages / TLB entries of both arrays (yinv 3.3 -> 2.8 ms)
+    const int ag = (L >= 1024) ? 32 : ngrp, az = (L >= 1024) ? 8 : 1;
+    TG = tn.ytile_g > 0 ? tn.ytile_g : ag; if (TG > ngrp) TG = ngrp; while (ngrp % TG) --TG;
+    TZ = tn.ytile_z > 0 ? tn.ytile_z : az; if (TZ > l) TZ = l;       while (l % TZ) --TZ;
 }
 template <class C, bool SPLIT> static void yfwd_t(const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
     constexpr int LINES = Tune<C>::LINES;
@@ -220,7 +227,7 @@ template <class C, bool SPLIT> static void yfwd_t(const PrunedTuning& tn, const 
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     auto k = k_yfwd<C, LINES, SPLIT>;
     allow_lds(k, lds);
-    int TG, TZ; ytile(tn, Lx / LINES, l, TG, TZ);
+    int TG, TZ; ytile(tn, C::L, Lx / LINES, l, TG, TZ);
     hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a1, a2, tw, Lx, m, l, TG, TZ);
 }
 template <class C, bool SPLIT> static void yinv_t(const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
@@ -229,7 +236,7 @@ template <class C, bool SPLIT> static void yinv_t(const PrunedTuning& tn, const 
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     auto k = k_yinv<C, LINES, SPLIT>;
     allow_lds(k, lds);
-    int TG, TZ; ytile(tn, Lx / LINES, l, TG, TZ);
+    int TG, TZ; ytile(tn, C::L, Lx / LINES, l, TG, TZ);
     hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l, TG, TZ);
 }
 template <class C, bool SPLIT, bool PREFETCH> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
@@ -283,7 +290,8 @@ PrunedTuning pruned_default_tuning() {
     PrunedTuning t;
     t.split_x = env_flag("LSFC_SPLIT_X", true);
     t.split_s = env_flag("LSFC_SPLIT_S", true);
-    t.sym_prefetch = env_flag("LSFC_SYM_PREFETCH", false);
+    if (const char* v = getenv("LSFC_SPLIT_Z")) t.split_z = atoi(v);
+    if (const char* v = getenv("LSFC_SYM_PREFETCH")) t.sym_prefetch = atoi(v);
     if (const char* v = getenv("LSFC_YTILE_G")) t.ytile_g = atoi(v);
     if (const char* v = getenv("LSFC_YTILE_Z")) t.ytile_z = atoi(v);
     return t;
@@ -316,8 +324,12 @@ void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const 
 void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, hipStream_t st) {
 #define LSFC_ZF(SP, PF) LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, st)))
-    if (tn.split_s) { if (tn.sym_prefetch) { LSFC_ZF(true, true); } else { LSFC_ZF(true, false); } }
-    else            { if (tn.sym_prefetch) { LSFC_ZF(false, true); } else { LSFC_ZF(false, false); } }
+    // auto (-1): measured on MI355X -- at L >= 1024 (16 elements/thread, 2 waves/SIMD either way) whole-complex
+    // exchanges + symbol prefetch win (7.4 -> 6.7 ms at 512^3); below, split exchanges without prefetch (more waves)
+    const bool sp = tn.split_z >= 0 ? tn.split_z != 0 : (L < 1024);
+    const bool pf = tn.sym_prefetch >= 0 ? tn.sym_prefetch != 0 : (L >= 1024);
+    if (sp) { if (pf) { LSFC_ZF(true, true); } else { LSFC_ZF(true, false); } }
+    else    { if (pf) { LSFC_ZF(false, true); } else { LSFC_ZF(false, false); } }
 #undef LSFC_ZF
     LSFC_HIP(hipGetLastError());
 }

@@ -438,7 +438,8 @@ int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value) {
         const std::string k(key);
         if (k == "split_x") plan->tuning.split_x = value != 0;
         else if (k == "split_s") plan->tuning.split_s = value != 0;
-        else if (k == "sym_prefetch") plan->tuning.sym_prefetch = value != 0;
+        else if (k == "split_z") plan->tuning.split_z = value;
+        else if (k == "sym_prefetch") plan->tuning.sym_prefetch = value;
         else if (k == "ytile_g") plan->tuning.ytile_g = value;
         else if (k == "ytile_z") plan->tuning.ytile_z = value;
         else fail(LSFC_EINVAL, "unknown tuning key '%s'", key);

@@ -6,9 +6,10 @@ namespace lsfc {
 
 struct PrunedTuning {
     bool split_x = true;   // contiguous (x) passes: exchange re/im separately (half the LDS, twice the barriers)
-    bool split_s = true;   // strided (y, z) passes
-    bool sym_prefetch = false;  // z pass: load the symbol before the forward transform (64 more VGPRs at E=16)
-    int ytile_g = 0, ytile_z = 0;   // y passes: block-order tile (x'-groups x z planes); 0 = all groups x 1 plane
+    bool split_s = true;   // strided y passes
+    int split_z = -1;      // fused z pass: 1 split, 0 whole complex, -1 auto (by line length)
+    int sym_prefetch = -1; // z pass: load the symbol before the forward transform; -1 auto
+    int ytile_g = 0, ytile_z = 0;   // y passes: block-order tile (x'-groups x z planes); 0 = auto
 };
 
 bool pruned_length_supported(int64_t L);

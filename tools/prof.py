@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fast_solver_lippmann_schwinger_amd as lsfc  # noqa: E402
 
 PEAK = 8.0e12
-BASE = dict(split_x=1, split_s=1, sym_prefetch=0, ytile_g=0, ytile_z=0)
+BASE = dict(split_x=1, split_s=1, split_z=-1, sym_prefetch=-1, ytile_g=0, ytile_z=0)
 
 
 def run(n, variants, reps=5):
@@ -43,17 +43,7 @@ def run(n, variants, reps=5):
 
 if __name__ == "__main__":
     ns = [int(a) for a in sys.argv[1:]] or [512]
-    variants = [("base", {}),
-                ("sym_prefetch", dict(sym_prefetch=1)),
-                ("split_s=0", dict(split_s=0)),
-                ("split_s=0 sym_prefetch", dict(split_s=0, sym_prefetch=1)),
-                ("ytile 16x16", dict(ytile_g=16, ytile_z=16)),
-                ("ytile 8x32", dict(ytile_g=8, ytile_z=32)),
-                ("ytile 32x8", dict(ytile_g=32, ytile_z=8)),
-                ("ytile 4x64", dict(ytile_g=4, ytile_z=64)),
-                ("ytile 1x256", dict(ytile_g=1, ytile_z=256)),
-                ("ytile 64x4", dict(ytile_g=64, ytile_z=4)),
-                ("ytile 2x128", dict(ytile_g=2, ytile_z=128)),
-                ("split_x=0", dict(split_x=0))]
+    variants = [("auto", {}),
+                ("old base", dict(split_z=1, sym_prefetch=0, ytile_g=4096, ytile_z=1))]
     for n in ns:
         run(n, variants)
