@@ -22,43 +22,65 @@ namespace lsfc {
     ::lsfc::fail(LSFC_EHIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); } while (0)
 
 DistState::~DistState() {
+    for (auto& v : { &ev_in, &ev_done, &ev_back }) for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
+    if (ev_p1) (void)hipEventDestroy(ev_p1);
+    if (cs1) (void)hipStreamDestroy(cs1);
+    if (cs2) (void)hipStreamDestroy(cs2);
+    if (comm2) (void)ncclCommDestroy((ncclComm_t)comm2);
     if (comm) (void)ncclCommDestroy((ncclComm_t)comm);
 }
 
-static int64_t block_elems(const lsfc_plan* p) { return (int64_t)p->dist->W * p->dims[1] * p->dist->lz; }
+// block of one (rank, chunk) pair in S1 / R1: [Wc][m][lz]
+static int64_t block_elems(const lsfc_plan* p) { return (int64_t)p->dist->Wc * p->dims[1] * p->dist->lz; }
 
-static void phase1(lsfc_plan* p, const cplx* x, bool use_nu) {
+static void phase1(lsfc_plan* p, const cplx* x, bool use_nu, hipStream_t st) {
     const DistState* d = p->dist.get();
-    pruned_xfwd(p->pads[0], p->tuning, x, use_nu ? p->nu.p : nullptr, d->S1.p, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->W, p->stream);
+    // chunk width Wc: storage index s of a line lands in block s / Wc = dest_rank * K + chunk
+    pruned_xfwd(p->pads[0], p->tuning, x, use_nu ? p->nu.p : nullptr, d->S1.p, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, st);
 }
-static void phase2(lsfc_plan* p) {
+static void phase2_yfwd(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
-    const int Ly = p->pads[1], Lz = p->pads[2], m = p->dims[1], l = p->dims[2], W = d->W;
-    hipStream_t st = p->stream;
-    pruned_yfwd(Ly, p->tuning, d->R1.p, p->A2.p, p->tw[1].p, W, m, l, st);
-    pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, W, Ly,
+    const int m = p->dims[1], l = p->dims[2];
+    pruned_yfwd(p->pads[1], p->tuning, d->R1.p + (int64_t)c * d->Wc * m * l, p->A2.p + (int64_t)c * d->Wc * p->pads[1] * l,
+                p->tw[1].p, d->Wc, m, l, st);
+}
+static void phase2_zfused(lsfc_plan* p, int c, hipStream_t st) {
+    const DistState* d = p->dist.get();
+    const int Ly = p->pads[1], Lz = p->pads[2], l = p->dims[2];
+    pruned_zfused(Lz, p->tuning, p->A2.p + (int64_t)c * d->Wc * Ly * l, p->sym.p + (int64_t)c * d->Wc * Ly * Lz, p->tw[2].p, d->Wc, Ly,
                   (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * Ly, (int64_t)8 * Lz, 8, st);
-    pruned_yinv(Ly, p->tuning, p->A2.p, d->R1.p, p->tw[1].p, W, m, l, st);
 }
-static void phase3(lsfc_plan* p, const cplx* x, cplx* y, double alpha, double beta) {
+static void phase2_yinv(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
-    pruned_xinv(p->pads[0], p->tuning, d->S1.p, x, y, alpha, beta, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->W, p->stream);
+    const int m = p->dims[1], l = p->dims[2];
+    pruned_yinv(p->pads[1], p->tuning, p->A2.p + (int64_t)c * d->Wc * p->pads[1] * l, d->R1.p + (int64_t)c * d->Wc * m * l,
+                p->tw[1].p, d->Wc, m, l, st);
+}
+static void phase2(lsfc_plan* p, int c, hipStream_t st) { phase2_yfwd(p, c, st); phase2_zfused(p, c, st); phase2_yinv(p, c, st); }
+static void phase3(lsfc_plan* p, const cplx* x, cplx* y, double alpha, double beta, hipStream_t st) {
+    const DistState* d = p->dist.get();
+    pruned_xinv(p->pads[0], p->tuning, d->S1.p, x, y, alpha, beta, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, st);
 }
 
-// all-to-all of equal blocks: block q of `send` goes to rank q, block q of `recv` comes from rank q
-static void exchange(lsfc_plan* p, const cplx* send, cplx* recv) {
+// Exchange of chunk c.  way in : S1 block (q*K + c)  -> rank q, lands in R1 chunk c at slot <source rank>
+//                       way back: R1 chunk c, slot q  -> rank q, lands in S1 block (<source rank>*K + c)
+static void exchange(lsfc_plan* p, int c, bool back, hipStream_t st) {
     DistState* d = p->dist.get();
     const int64_t B = block_elems(p);
-    hipStream_t st = p->stream;
-    LSFC_HIP(hipMemcpyAsync(recv + d->rank * B, send + d->rank * B, (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice, st));
-    if (d->nranks == 1) return;
-    ncclComm_t comm = (ncclComm_t)d->comm;
+    const int K = d->K, P = d->nranks;
+    auto s1 = [&](int r) { return d->S1.p + ((int64_t)r * K + c) * B; };
+    auto r1 = [&](int r) { return d->R1.p + ((int64_t)c * P + r) * B; };
+    const cplx* self_src = back ? r1(d->rank) : s1(d->rank);
+    cplx* self_dst = back ? s1(d->rank) : r1(d->rank);
+    LSFC_HIP(hipMemcpyAsync(self_dst, self_src, (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice, st));
+    if (P == 1) return;
+    ncclComm_t comm = (ncclComm_t)(back ? d->comm2 : d->comm);
     LSFC_NCCL(ncclGroupStart());
-    for (int s = 1; s < d->nranks; ++s) {
-        // pairwise schedule: every GPU talks to a different peer in step s (all xGMI links busy at once)
-        const int to = (d->rank + s) % d->nranks, from = (d->rank - s + d->nranks) % d->nranks;
-        LSFC_NCCL(ncclSend(send + to * B, (size_t)B * 2, ncclDouble, to, comm, st));
-        LSFC_NCCL(ncclRecv(recv + from * B, (size_t)B * 2, ncclDouble, from, comm, st));
+    for (int s = 1; s < P; ++s) {
+        // pairwise schedule: in step s every GPU talks to a different peer, so all xGMI links carry traffic at once
+        const int to = (d->rank + s) % P, from = (d->rank - s + P) % P;
+        LSFC_NCCL(ncclSend(back ? r1(to) : s1(to), (size_t)B * 2, ncclDouble, to, comm, st));
+        LSFC_NCCL(ncclRecv(back ? s1(from) : r1(from), (size_t)B * 2, ncclDouble, from, comm, st));
     }
     LSFC_NCCL(ncclGroupEnd());
 }
@@ -66,11 +88,33 @@ static void exchange(lsfc_plan* p, const cplx* send, cplx* recv) {
 void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta) {
     DistState* d = p->dist.get();
     LSFC_REQUIRE(!d->sim, "simulated ranks are driven through lsfc_dist_sim_apply");
-    phase1(p, x, use_nu);
-    exchange(p, d->S1.p, d->R1.p);
-    phase2(p);
-    exchange(p, d->R1.p, d->S1.p);
-    phase3(p, x, y, alpha, beta);
+    hipStream_t st = p->stream;
+    phase1(p, x, use_nu, st);
+    if (d->nranks == 1) {
+        for (int c = 0; c < d->K; ++c) { exchange(p, c, false, st); phase2(p, c, st); exchange(p, c, true, st); }
+        phase3(p, x, y, alpha, beta, st);
+        return;
+    }
+    // software pipeline over the K chunks of the owned x' range: the all-to-all of chunk c+1 (stream cs1) and the
+    // all-to-all back of chunk c-1 (stream cs2, second communicator) run while chunk c is transformed (stream st)
+    LSFC_HIP(hipEventRecord(d->ev_p1, st));
+    LSFC_HIP(hipStreamWaitEvent(d->cs1, d->ev_p1, 0));
+    LSFC_HIP(hipStreamWaitEvent(d->cs2, d->ev_p1, 0));      // also orders cs2 after the previous apply's xinv reads of S1
+    for (int c = 0; c < d->K; ++c) {
+        exchange(p, c, false, d->cs1);
+        LSFC_HIP(hipEventRecord(d->ev_in[c], d->cs1));
+    }
+    for (int c = 0; c < d->K; ++c) {
+        LSFC_HIP(hipStreamWaitEvent(st, d->ev_in[c], 0));
+        phase2(p, c, st);
+        LSFC_HIP(hipEventRecord(d->ev_done[c], st));
+        LSFC_HIP(hipStreamWaitEvent(d->cs2, d->ev_done[c], 0));
+        // (the S1 blocks this receive overwrites belong to chunk c, whose way-in sends finished before ev_in[c])
+        exchange(p, c, true, d->cs2);
+        LSFC_HIP(hipEventRecord(d->ev_back[c], d->cs2));
+    }
+    for (int c = 0; c < d->K; ++c) LSFC_HIP(hipStreamWaitEvent(st, d->ev_back[c], 0));
+    phase3(p, x, y, alpha, beta, st);
 }
 
 void dist_allreduce_sum(lsfc_plan* p, cplx* dev, int count) {
@@ -82,16 +126,16 @@ void dist_allreduce_sum(lsfc_plan* p, cplx* dev, int count) {
 void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y, std::function<void(const char*, double, std::function<void()>)> add) {
     DistState* d = p->dist.get();
     const double N = (double)p->N, C = 16.0, om2 = p->omega * p->omega;     // N = local points
-    const int Ly = p->pads[1], Lz = p->pads[2], m = p->dims[1], l = p->dims[2], W = d->W;
     hipStream_t st = p->stream;
-    add("xfwd", N * (C + 8) + 2 * N * C, [=] { phase1(p, x, true); });
-    add("alltoall1", 2 * N * C, [=] { exchange(p, d->S1.p, d->R1.p); });
-    add("yfwd", 6 * N * C, [=] { pruned_yfwd(Ly, p->tuning, d->R1.p, p->A2.p, p->tw[1].p, W, m, l, st); });
-    add("zfused", 16 * N * C, [=] { pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, W, Ly,
-                                   (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * Ly, (int64_t)8 * Lz, 8, st); });
-    add("yinv", 6 * N * C, [=] { pruned_yinv(Ly, p->tuning, p->A2.p, d->R1.p, p->tw[1].p, W, m, l, st); });
-    add("alltoall2", 2 * N * C, [=] { exchange(p, d->R1.p, d->S1.p); });
-    add("xinv", 4 * N * C, [=] { phase3(p, x, y, 1.0, om2); });
+    const int K = d->K;
+    // un-overlapped, stage by stage, all on the plan's stream (the production path overlaps the exchanges)
+    add("xfwd", N * (C + 8) + 2 * N * C, [=] { phase1(p, x, true, st); });
+    add("alltoall_in", 2 * N * C, [=] { for (int c = 0; c < K; ++c) exchange(p, c, false, st); });
+    add("yfwd", 6 * N * C, [=] { for (int c = 0; c < K; ++c) phase2_yfwd(p, c, st); });
+    add("zfused", 16 * N * C, [=] { for (int c = 0; c < K; ++c) phase2_zfused(p, c, st); });
+    add("yinv", 6 * N * C, [=] { for (int c = 0; c < K; ++c) phase2_yinv(p, c, st); });
+    add("alltoall_back", 2 * N * C, [=] { for (int c = 0; c < K; ++c) exchange(p, c, true, st); });
+    add("xinv", 4 * N * C, [=] { phase3(p, x, y, 1.0, om2, st); });
 }
 
 // ---------------------------------------------------------------------------
@@ -123,13 +167,31 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     p->dist.reset(new DistState());
     DistState* d = p->dist.get();
     d->rank = rank; d->nranks = nranks; d->sim = sim; d->lz = lz; d->W = p->pads[0] / nranks;
+    // pipeline chunks: up to 4, each at least one 8-wide tile (LSFC_DIST_CHUNKS overrides; 1 disables the overlap)
+    int K = 4;
+    if (const char* v = getenv("LSFC_DIST_CHUNKS")) K = atoi(v);
+    if (nranks == 1 && !sim && !getenv("LSFC_DIST_CHUNKS")) K = 1;
+    if (K < 1) K = 1;
+    while (K > 1 && (d->W % K != 0 || (d->W / K) % 8 != 0)) --K;
+    d->K = K; d->Wc = d->W / K;
     if (!sim && nranks > 1) {
         LSFC_REQUIRE(id, "NULL unique id");
         ncclUniqueId uid; static_assert(sizeof(uid) == LSFC_UNIQUE_ID_BYTES, "unique id size");
         memcpy(&uid, id, sizeof uid);
-        ncclComm_t comm;
+        ncclComm_t comm, comm2;
         LSFC_NCCL(ncclCommInitRank(&comm, nranks, uid, rank));
         d->comm = comm;
+        LSFC_NCCL(ncclCommSplit(comm, 0, rank, &comm2, nullptr));
+        d->comm2 = comm2;
+        LSFC_HIP(hipStreamCreateWithFlags(&d->cs1, hipStreamNonBlocking));
+        LSFC_HIP(hipStreamCreateWithFlags(&d->cs2, hipStreamNonBlocking));
+        LSFC_HIP(hipEventCreateWithFlags(&d->ev_p1, hipEventDisableTiming));
+        d->ev_in.resize((size_t)K); d->ev_done.resize((size_t)K); d->ev_back.resize((size_t)K);
+        for (int c = 0; c < K; ++c) {
+            LSFC_HIP(hipEventCreateWithFlags(&d->ev_in[c], hipEventDisableTiming));
+            LSFC_HIP(hipEventCreateWithFlags(&d->ev_done[c], hipEventDisableTiming));
+            LSFC_HIP(hipEventCreateWithFlags(&d->ev_back[c], hipEventDisableTiming));
+        }
     }
     // symbol: every rank evaluates the reduced symbol (elementary functions + rocFFT, ~3.5 s at 512^3) and keeps
     // only the slab of its own x' tiles in the tiled storage order
@@ -199,17 +261,24 @@ int lsfc_dist_sim_apply(lsfc_plan** plans, int nranks, const double* const* x, d
             LSFC_HIP(hipMemcpy(p->xs.p, x[r], (size_t)p->N * sizeof(cplx), hipMemcpyHostToDevice));
             xd[r] = p->xs.p; yd[r] = p->ys.p;
         }
-        for (int r = 0; r < nranks; ++r) phase1(plans[r], xd[r], mode != 1);
+        const int K = plans[0]->dist->K;
+        for (int r = 0; r < nranks; ++r) phase1(plans[r], xd[r], mode != 1, plans[r]->stream);
         sync_all();
-        for (int r = 0; r < nranks; ++r) for (int q = 0; q < nranks; ++q)        // block q of rank r -> slot r of rank q
-            LSFC_HIP(hipMemcpy(plans[q]->dist->R1.p + r * B, plans[r]->dist->S1.p + q * B, (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice));
-        for (int r = 0; r < nranks; ++r) phase2(plans[r]);
-        sync_all();
-        for (int r = 0; r < nranks; ++r) for (int q = 0; q < nranks; ++q)
-            LSFC_HIP(hipMemcpy(plans[q]->dist->S1.p + r * B, plans[r]->dist->R1.p + q * B, (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice));
+        for (int c = 0; c < K; ++c) {
+            // way in: block (q*K + c) of rank r's S1 -> slot r of chunk c of rank q's R1
+            for (int r = 0; r < nranks; ++r) for (int q = 0; q < nranks; ++q)
+                LSFC_HIP(hipMemcpy(plans[q]->dist->R1.p + ((int64_t)c * nranks + r) * B, plans[r]->dist->S1.p + ((int64_t)q * K + c) * B,
+                                   (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice));
+            for (int r = 0; r < nranks; ++r) phase2(plans[r], c, plans[r]->stream);
+            sync_all();
+            // way back: slot q of chunk c of rank r's R1 -> block (r*K + c) of rank q's S1
+            for (int r = 0; r < nranks; ++r) for (int q = 0; q < nranks; ++q)
+                LSFC_HIP(hipMemcpy(plans[q]->dist->S1.p + ((int64_t)r * K + c) * B, plans[r]->dist->R1.p + ((int64_t)c * nranks + q) * B,
+                                   (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice));
+        }
         for (int r = 0; r < nranks; ++r) {
             lsfc_plan* p = plans[r];
-            if (mode == 0) phase3(p, xd[r], yd[r], 1.0, p->omega * p->omega); else phase3(p, xd[r], yd[r], 0.0, 1.0);
+            if (mode == 0) phase3(p, xd[r], yd[r], 1.0, p->omega * p->omega, p->stream); else phase3(p, xd[r], yd[r], 0.0, 1.0, p->stream);
         }
         sync_all();
         for (int r = 0; r < nranks; ++r) LSFC_HIP(hipMemcpy(y[r], yd[r], (size_t)plans[r]->N * sizeof(cplx), hipMemcpyDeviceToHost));

@@ -46,10 +46,16 @@ struct DistState {
     int rank = 0, nranks = 1;
     bool sim = false;        // simulated ranks in one process (tests): exchanges done by lsfc_dist_sim_apply
     void* comm = nullptr;    // ncclComm_t
+    void* comm2 = nullptr;   // second communicator: the way back runs on its own stream, concurrently with the way in
     int lz = 0;              // local z planes (l / nranks)
     int W = 0;               // x' storage indices owned after the transpose (Lx / nranks)
-    DevBuf<cplx> S1;         // [nranks][W][m][lz]: xfwd output packed per destination rank / xinv input
-    DevBuf<cplx> R1;         // [W][m][l]: natural layout on the owned x' range (concatenation of received blocks)
+    int K = 1;               // pipeline chunks of the owned x' range (exchange of chunk c+1 overlaps compute on chunk c)
+    int Wc = 0;              // W / K
+    DevBuf<cplx> S1;         // [nranks][K][Wc][m][lz]: xfwd output packed per (destination rank, chunk) / xinv input
+    DevBuf<cplx> R1;         // [K][Wc][m][l]: per chunk the natural layout on its x' range (received blocks concatenated)
+    hipStream_t cs1 = nullptr, cs2 = nullptr;      // communication streams (in / back)
+    std::vector<hipEvent_t> ev_in, ev_done, ev_back;
+    hipEvent_t ev_p1 = nullptr;
     ~DistState();
 };
 

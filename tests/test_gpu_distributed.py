@@ -37,3 +37,24 @@ def test_simulated_ranks_noncubic_equals_single_gpu(lsfc):
         assert rel_err(S.apply(b), ref) < 1e-13
         assert rel_err(S.convolve(b, apply_nu=True), (ref - b) / k**2) < 1e-11
         S.close()
+
+
+@pytest.mark.parametrize("chunks", ["1", "4"])
+def test_distributed_plan_single_rank_production_path(lsfc, chunks, monkeypatch):
+    # the real (non-simulated) distributed plan with one rank: chunk-packed x passes, chunk loop, profile stages, GMRES
+    from fast_solver_lippmann_schwinger_amd.distributed import build_distributed_3d
+    monkeypatch.setenv("LSFC_DIST_CHUNKS", chunks)
+    c = cases.case_3d("gv32k10")
+    Mo, b, n = c["M"], c["b"], c["n"]
+    M = build_distributed_3d(n, c["h"], c["k"], Mo.nu, 0, 1, 0)
+    assert rel_err(M * b, o.mul(Mo, b)) < TOL
+    assert rel_err(lsfc.FFTconvolution(M, b), o.fft_convolution(Mo, b)) < TOL
+    import torch
+    xb = torch.from_numpy(b).cuda(); yb = torch.empty_like(xb)
+    names = [s[0] for s in lsfc.profile_apply(M, xb, yb, 1)]
+    assert names == ["xfwd", "alltoall_in", "yfwd", "zfused", "yinv", "alltoall_back", "xinv"]
+    u_inc = cases.plane_wave(c["k"], c["X"])
+    rhs = -(M * u_inc - u_inc)
+    u = np.zeros(M.N, complex)
+    u, hist = lsfc.gmres_(u, M, rhs, restart=10, reltol=1e-8, log=True)
+    assert hist.isconverged and np.linalg.norm(o.mul(Mo, u) - rhs) / np.linalg.norm(rhs) < 1e-7
