@@ -1,0 +1,87 @@
+"""Secondary measurements for the BASELINE.json configs that are not the bench.py headline:
+  configs[1]  2D n=1024 fp64 apply on one MI355X
+  configs[2]  3D n=256 fp64, full GMRES(30) solve to 1e-6 (rhs from a plane wave, examples/example3D.jl:71-78)
+  configs[4]  3D n=512 at omega = 64 pi (lattice points on |s| = k, patched symbol): apply rate + finite check
+usage: python tools/bench_configs.py [2d] [gmres] [hf]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fast_solver_lippmann_schwinger_amd as lsfc  # noqa: E402
+
+
+def bump(*c):
+    r2 = sum(x ** 2 for x in c)
+    out = 0.3 * np.exp(-40 * r2)
+    for x in c:
+        out = out * (np.abs(x) < 0.48)
+    return out
+
+
+def bench_2d(n=1024):
+    h = 1.0 / (n - 1)
+    x = -0.5 + h * np.arange(n)
+    k = 1.0 / h
+    M = lsfc.buildFastConvolution(x, x, h, k, lambda X, Y: bump(X, Y), quadRule="Greengard_Vico")
+    N = n * n
+    xb = torch.randn(N, dtype=torch.complex128, device="cuda"); yb = torch.empty_like(xb)
+    lsfc.time_apply(M, xb, yb, 20)
+    ms = min(lsfc.time_apply(M, xb, yb, 200) / 200 for _ in range(3))
+    st = lsfc.profile_apply(M, xb, yb, 20)
+    return {"config": f"2D n={n} fp64 apply", "pipeline": M.pipeline, "ms_per_apply": ms, "applies_per_s": 1e3 / ms,
+            "algorithmic_GBps": 248.0 * N / (ms * 1e-3) / 1e9, "stages": {s: t for s, t, _ in st}}
+
+
+def bench_gmres(n=256, restart=30, reltol=1e-6):
+    h = 1.0 / n
+    x = -0.5 + h * np.arange(n)
+    k = 1.0 / h
+    X = np.tile(x, n * n)                                  # x fastest
+    Y = np.tile(np.repeat(x, n), n)
+    Z = np.repeat(x, n * n)
+    nu = bump(X, Y, Z)
+    t0 = time.time()
+    M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, k, nu)
+    t_plan = time.time() - t0
+    u_inc = torch.from_numpy(np.exp(1j * k * X)).cuda()
+    rhs = -(M * u_inc - u_inc)
+    out = {}
+    for orth in ["ModifiedGramSchmidt", "ClassicalGramSchmidt"]:
+        u = torch.zeros_like(rhs)
+        torch.cuda.synchronize(); t0 = time.time()
+        u, hist = lsfc.gmres_(u, M, rhs, restart=restart, reltol=reltol, log=True, orth_meth=orth)
+        torch.cuda.synchronize(); t = time.time() - t0
+        res = float(torch.linalg.norm(M * u - rhs) / torch.linalg.norm(rhs))
+        out[orth] = {"iters": hist.iters, "mvps": hist.mvps, "converged": hist.isconverged, "seconds": t,
+                     "ms_per_iteration": 1e3 * t / max(hist.iters, 1), "true_relres": res, "final_resnorm": float(hist["resnorm"][-1])}
+    yb = torch.empty_like(rhs)
+    ms = lsfc.time_apply(M, rhs, yb, 20) / 20
+    return {"config": f"3D n={n} GMRES({restart}) reltol={reltol:g}", "plan_seconds": t_plan, "apply_ms": ms, "solves": out}
+
+
+def bench_hf(n=512):
+    h = 1.0 / n
+    x = -0.5 + h * np.arange(n)
+    k = 64 * np.pi
+    rng = np.random.default_rng(0)
+    nu = rng.uniform(-0.3, 0.3, n ** 3)
+    M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, k, nu, flags=4)          # LSFC_FLAG_PATCH_SINGULAR
+    xb = torch.randn(n ** 3, dtype=torch.complex128, device="cuda"); yb = torch.empty_like(xb)
+    lsfc.time_apply(M, xb, yb, 2)
+    ms = lsfc.time_apply(M, xb, yb, 10) / 10
+    return {"config": f"3D n={n} omega=64pi patched symbol", "ms_per_apply": ms, "finite": bool(torch.isfinite(torch.view_as_real(yb)).all())}
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["2d", "gmres", "hf"]
+    res = []
+    if "2d" in what: res.append(bench_2d())
+    if "gmres" in what: res.append(bench_gmres())
+    if "hf" in what: res.append(bench_hf())
+    for r in res:
+        print(json.dumps(r), flush=True)
