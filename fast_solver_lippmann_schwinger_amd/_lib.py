@@ -52,6 +52,7 @@ SIGNATURES = {
     "lsfc_apply": (_I, [_P, _P, _P, _I]),
     "lsfc_convolve": (_I, [_P, _P, _P, _I, _I]),
     "lsfc_apply_batch": (_I, [_P, _P, _P, _L, _I, _I]),
+    "lsfc_sample_sources": (_I, [_P, _P, _L, _P, _I]),
     "lsfc_gmres": (_I, [_P, _P, _P, C.POINTER(GmresOpts), _P, _L, C.POINTER(GmresResult), _I]),
     "lsfc_plan_set_stream": (_I, [_P, _P]),
     "lsfc_plan_synchronize": (_I, [_P]),

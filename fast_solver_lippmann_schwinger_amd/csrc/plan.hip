@@ -366,6 +366,7 @@ const char* lsfc_plan_pipeline(const lsfc_plan* plan) {
     }
 }
 
+// (kernel0 does not depend on nu: lsfc_plan_set_nu keeps it)
 int lsfc_plan_set_nu(lsfc_plan* plan, const double* nu, int memspace) {
     return guarded([&] {
         LSFC_REQUIRE(plan && nu, "NULL argument");
@@ -399,6 +400,43 @@ int lsfc_apply_batch(lsfc_plan* plan, const double* x, double* y, int64_t nrhs, 
         LSFC_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (apply), 1 (convolve) or 2 (convolve with nu)");
         if (mode == 0) convolve_any(plan, x, y, nrhs, true, 1.0, plan->omega * plan->omega, memspace);
         else convolve_any(plan, x, y, nrhs, mode == 2, 0.0, 1.0, memspace);
+    });
+}
+
+int lsfc_sample_sources(lsfc_plan* plan, const int64_t* sources, int64_t nsrc, double* out, int memspace) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan && sources && out && nsrc >= 1, "bad argument");
+        LSFC_REQUIRE(!plan->dist, "not available on a distributed plan");
+        LSFC_HIP(hipSetDevice(plan->device));
+        lsfc_plan* p = plan;
+        const int64_t N = p->N;
+        for (int64_t s = 0; s < nsrc; ++s) LSFC_REQUIRE(sources[s] >= 0 && sources[s] < N, "source index %lld out of range", (long long)sources[s]);
+        // kernel samples: the response to a unit source at grid index 0 (one FFT convolution, no nu)
+        if (p->kernel0.n != (size_t)N) {
+            p->kernel0.alloc((size_t)N);
+            DevBuf<cplx> e; e.alloc((size_t)N);
+            LSFC_HIP(hipMemsetAsync(e.p, 0, (size_t)N * sizeof(cplx), p->stream));
+            const cplx one = make_double2(1.0, 0.0);
+            LSFC_HIP(hipMemcpyAsync(e.p, &one, sizeof one, hipMemcpyHostToDevice, p->stream));
+            plan_convolve_dev(p, e.p, p->kernel0.p, false, 0.0, 1.0);
+            LSFC_HIP(hipStreamSynchronize(p->stream));
+        }
+        DevBuf<int64_t> dsrc; dsrc.alloc((size_t)nsrc);
+        LSFC_HIP(hipMemcpyAsync(dsrc.p, sources, (size_t)nsrc * sizeof(int64_t), hipMemcpyHostToDevice, p->stream));
+        if (memspace == LSFC_MEM_DEVICE) {
+            pw_gather_sources(p->kernel0.p, (cplx*)out, dsrc.p, (int)nsrc, p->dims, p->stream);
+            LSFC_HIP(hipStreamSynchronize(p->stream));
+        } else {
+            // stage in batches of at most ~256 MiB
+            const int64_t per = std::max<int64_t>(1, ((int64_t)1 << 24) / N);
+            DevBuf<cplx> buf; buf.alloc((size_t)(std::min(per, nsrc) * N));
+            for (int64_t s0 = 0; s0 < nsrc; s0 += per) {
+                const int64_t cnt = std::min(per, nsrc - s0);
+                pw_gather_sources(p->kernel0.p, buf.p, dsrc.p + s0, (int)cnt, p->dims, p->stream);
+                LSFC_HIP(hipMemcpyAsync((cplx*)out + s0 * N, buf.p, (size_t)(cnt * N) * sizeof(cplx), hipMemcpyDeviceToHost, p->stream));
+                LSFC_HIP(hipStreamSynchronize(p->stream));
+            }
+        }
     });
 }
 

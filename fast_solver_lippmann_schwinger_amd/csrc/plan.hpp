@@ -86,6 +86,10 @@ struct lsfc_plan {
     std::unique_ptr<lsfc::RocFft> fwd, inv;
     lsfc::DevBuf<lsfc::cplx> W;
 
+    // response to a unit source at grid index 0 (the spatial kernel on [0,n)^d), built on first use by
+    // lsfc_sample_sources
+    lsfc::DevBuf<lsfc::cplx> kernel0;
+
     // staging for host-resident vectors
     lsfc::DevBuf<lsfc::cplx> xs, ys;
 

@@ -140,6 +140,27 @@ void pw_scale(cplx* a, double s, int64_t total, hipStream_t st) {
     LSFC_HIP(hipGetLastError());
 }
 
+// ---- delta-source sampling (sampleG3D / sampleGConv) ---------------------------------------
+// out[s][i] = K[|i0-j0|][|i1-j1|][|i2-j2|] for source s at grid index j: the response to a unit source is the
+// spatial kernel shifted to the source, and the kernel is even in every axis, so ONE convolution (source at the
+// origin corner) serves every source by a gather.
+__global__ void k_gather_sources(const cplx* __restrict__ K, cplx* __restrict__ out, const int64_t* __restrict__ src, int nsrc,
+                                 int n, int m, int l) {
+    const int64_t N = (int64_t)n * m * l, total = N * nsrc;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(idx / N); const int64_t i = idx % N, j = src[s];
+        const int i0 = (int)(i % n), i1 = (int)((i / n) % m), i2 = (int)(i / ((int64_t)n * m));
+        const int j0 = (int)(j % n), j1 = (int)((j / n) % m), j2 = (int)(j / ((int64_t)n * m));
+        const int d0 = abs(i0 - j0), d1 = abs(i1 - j1), d2 = abs(i2 - j2);
+        out[idx] = K[d0 + (int64_t)n * (d1 + (int64_t)m * d2)];
+    }
+}
+void pw_gather_sources(const cplx* K, cplx* out, const int64_t* src, int nsrc, const int dims[3], hipStream_t st) {
+    const int64_t total = (int64_t)dims[0] * dims[1] * dims[2] * nsrc;
+    hipLaunchKernelGGL(k_gather_sources, dim3(grid_for(total)), dim3(256), 0, st, K, out, src, nsrc, dims[0], dims[1], dims[2]);
+    LSFC_HIP(hipGetLastError());
+}
+
 // ---- GMRES BLAS-1 ------------------------------------------------------------
 // Reductions: each block accumulates a grid-stride slice, reduces across its four
 // waves (shuffle, then LDS), and writes one partial; a single-wave finisher sums

@@ -16,6 +16,8 @@ void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], do
 void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* py, const int* pz, const int L[3], int xb0, int ntiles, double scale, hipStream_t);
 void pw_scale(cplx* a, double s, int64_t total, hipStream_t);
 
+void pw_gather_sources(const cplx* K, cplx* out, const int64_t* src, int nsrc, const int dims[3], hipStream_t);
+
 // GMRES BLAS-1 (results land in device scalars; `partial` is scratch of blas_partial_count() entries)
 int  blas_partial_count();
 void blas_dot(const cplx* a, const cplx* b, cplx* partial, cplx* out, int64_t n, hipStream_t);          // out = a' * b

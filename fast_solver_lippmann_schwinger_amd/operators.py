@@ -296,12 +296,18 @@ def sampleG3D(k, X, Y, Z, indS, fastconv):
 
 def _sample(indS, M):
     N, ns = M.N, len(indS)
-    R = np.zeros((ns, N), dtype=np.complex128)
-    for i, ii in enumerate(indS):
-        R[i, ii] = 1.0
-    out = np.empty_like(R)
-    mode = 2 if (isinstance(M, FastM) and M.quadRule == "trapezoidal") else 1
-    L.check(L.load().lsfc_apply_batch(M._plan, R.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), ns, mode, L.LSFC_MEM_HOST))
+    out = np.empty((ns, N), dtype=np.complex128)
+    if isinstance(M, FastM) and M.quadRule == "trapezoidal":
+        # the reference's trapezoidal FFTconvolution multiplies the source by nu (src/FastConvolution.jl:122):
+        # keep that quirk literally, one convolution per source
+        R = np.zeros((ns, N), dtype=np.complex128)
+        for i, ii in enumerate(indS):
+            R[i, ii] = 1.0
+        L.check(L.load().lsfc_apply_batch(M._plan, R.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), ns, 2, L.LSFC_MEM_HOST))
+        return out
+    # Greengard-Vico: rows of the Green's matrix = shifted copies of the (even) kernel -> one convolution + gathers
+    src = np.ascontiguousarray(indS, dtype=np.int64)
+    L.check(L.load().lsfc_sample_sources(M._plan, src.ctypes.data_as(C.c_void_p), ns, out.ctypes.data_as(C.c_void_p), L.LSFC_MEM_HOST))
     return out
 
 

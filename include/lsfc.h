@@ -132,6 +132,15 @@ int lsfc_convolve(lsfc_plan* plan, const double* x, double* y, int apply_nu, int
  * multi-source callers (sampleG3D, src/FastConvolution3D.jl:136-160). */
 int lsfc_apply_batch(lsfc_plan* plan, const double* x, double* y, int64_t nrhs, int mode /*0 apply,1 convolve,2 convolve+nu*/, int memspace);
 
+/* Rows of the discrete Green's matrix for the delta sources at grid indices sources[0..nsrc): out + s*N receives
+ * FFTconvolution(M, e_{sources[s]}).  Replaces sampleGConv / sampleG3D(..., fastconv) (src/FastConvolution.jl:278-306,
+ * src/FastConvolution3D.jl:136-160), which run one full FFT convolution per source (O(10^3) of them in the
+ * preconditioner set-up).  Here the spatial kernel is obtained ONCE (one convolution of a unit source at index 0)
+ * and every row is a gather K[|i - j|] -- the kernel is even in every axis -- so the cost per source is one
+ * N-vector write.  (2D trapezoidal plans: as in the reference's FFTconvolution, nu is NOT applied to a delta row
+ * by this entry; use lsfc_apply_batch for that quirk.) */
+int lsfc_sample_sources(lsfc_plan* plan, const int64_t* sources, int64_t nsrc, double* out, int memspace);
+
 /* ---- GMRES ---------------------------------------------------------------- */
 
 /* In-place left preconditioner, mirrors the two-argument ldiv!(Pl, v)

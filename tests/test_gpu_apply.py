@@ -180,6 +180,27 @@ def test_sample_g3d_delta_sources(lsfc):
     assert rel_err(lsfc.sampleG3D(Mo.omega, None, None, None, indS, M), o.sample_g_conv(indS, Mo)) < TOL
 
 
+def test_sample_sources_gather_2d_and_noncubic(lsfc):
+    # GV 2D (sampleGConv) and a non-cubic 3D grid: gather path == one FFT convolution per source
+    c = cases.case_2d("gv32")
+    M = lsfc.buildFastConvolution(c["x"], c["x"], c["h"], c["k"], c["nu"], quadRule="Greengard_Vico")
+    ind = [0, 5 + 32 * 7, 31, 32 * 32 - 1]
+    assert rel_err(lsfc.sampleGConv(c["k"], None, None, ind, M), o.sample_g_conv(ind, c["M"])) < TOL
+    n, m, l = 16, 32, 64
+    h = 1.0 / n
+    x = -0.5 + h * np.arange(n)
+    M3 = lsfc.buildFastConvolution3D(x, x[:1].repeat(m), x[:1].repeat(l), None, None, None, h, 6.0, np.zeros(n * m * l))
+    ind3 = [0, 3 + n * (17 + m * 40), n * m * l - 1]
+    rows = lsfc.sampleG3D(6.0, None, None, None, ind3, M3)
+    for r, j in zip(rows, ind3):
+        e = np.zeros(n * m * l, complex); e[j] = 1
+        assert rel_err(r, lsfc.FFTconvolution(M3, e)) < 1e-12
+    # trapezoidal keeps the reference's nu quirk (one convolution per source)
+    ct = cases.case_2d("trap21")
+    Mt = lsfc.buildFastConvolution(ct["x"], ct["x"], ct["h"], ct["k"], ct["nu"], quadRule="trapezoidal")
+    assert rel_err(lsfc.sampleGConv(ct["k"], None, None, [7, 100], Mt), o.sample_g_conv([7, 100], ct["M"])) < TOL
+
+
 def test_set_nu_and_aliasing(lsfc):
     c = cases.case_3d("gv16")
     Mo, b, n = c["M"], c["b"], c["n"]
