@@ -36,30 +36,30 @@ static int64_t block_elems(const lsfc_plan* p) { return (int64_t)p->dist->Wc * p
 static void phase1(lsfc_plan* p, const cplx* x, bool use_nu, hipStream_t st) {
     const DistState* d = p->dist.get();
     // chunk width Wc: storage index s of a line lands in block s / Wc = dest_rank * K + chunk
-    pruned_xfwd(p->pads[0], p->tuning, x, use_nu ? p->nu.p : nullptr, d->S1.p, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, st);
+    pruned_xfwd(p->pads[0], p->tuning, x, use_nu ? p->nu.p : nullptr, d->S1.p, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, d->Wc, st);
 }
 static void phase2_yfwd(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
     const int m = p->dims[1], l = p->dims[2];
     pruned_yfwd(p->pads[1], p->tuning, d->R1.p + (int64_t)c * d->Wc * m * l, p->A2.p + (int64_t)c * d->Wc * p->pads[1] * l,
-                p->tw[1].p, d->Wc, m, l, st);
+                p->tw[1].p, d->Wc, m, l, d->Wc, 8 * l, st);
 }
 static void phase2_zfused(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
     const int Ly = p->pads[1], Lz = p->pads[2], l = p->dims[2];
-    pruned_zfused(Lz, p->tuning, p->A2.p + (int64_t)c * d->Wc * Ly * l, p->sym.p + (int64_t)c * d->Wc * Ly * Lz, p->tw[2].p, d->Wc, Ly,
-                  (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * Ly, (int64_t)8 * Lz, 8, st);
+    pruned_zfused(Lz, p->tuning, p->A2.p + (int64_t)c * d->Wc * Ly * l, p->sym.p + (int64_t)c * d->Wc * p->sym_rows * Lz, p->tw[2].p, d->Wc, Ly,
+                  (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * p->sym_rows, (int64_t)8 * Lz, 8, p->ytab.p, st);
 }
 static void phase2_yinv(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
     const int m = p->dims[1], l = p->dims[2];
     pruned_yinv(p->pads[1], p->tuning, p->A2.p + (int64_t)c * d->Wc * p->pads[1] * l, d->R1.p + (int64_t)c * d->Wc * m * l,
-                p->tw[1].p, d->Wc, m, l, st);
+                p->tw[1].p, d->Wc, m, l, d->Wc, 8 * l, st);
 }
 static void phase2(lsfc_plan* p, int c, hipStream_t st) { phase2_yfwd(p, c, st); phase2_zfused(p, c, st); phase2_yinv(p, c, st); }
 static void phase3(lsfc_plan* p, const cplx* x, cplx* y, double alpha, double beta, hipStream_t st) {
     const DistState* d = p->dist.get();
-    pruned_xinv(p->pads[0], p->tuning, d->S1.p, x, y, alpha, beta, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, st);
+    pruned_xinv(p->pads[0], p->tuning, d->S1.p, x, y, alpha, beta, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, d->Wc, st);
 }
 
 // Exchange of chunk c.  way in : S1 block (q*K + c)  -> rank q, lands in R1 chunk c at slot <source rank>
@@ -200,15 +200,17 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     std::vector<int> perm[3]; DevBuf<int> dperm[3];
     for (int a = 0; a < 3; ++a) {
         perm[a].resize((size_t)p->pads[a]);
-        pruned_perm(p->pads[a], perm[a].data());
+        pruned_perm(p->pads[a], a == 1 ? p->tuning.cfg_y : (a == 2 ? p->tuning.cfg_z : 0), perm[a].data());
         dperm[a].alloc(perm[a].size());
         LSFC_HIP(hipMemcpy(dperm[a].p, perm[a].data(), perm[a].size() * sizeof(int), hipMemcpyHostToDevice));
         make_twiddles_dist(p.get(), a, p->pads[a]);
     }
     const int ntiles = d->W / 8;
     const double scale = 1.0 / ((double)p->pads[0] * p->pads[1] * p->pads[2]);
-    p->sym.alloc((size_t)d->W * p->pads[1] * p->pads[2]);
-    pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, rank * ntiles, ntiles, scale, p->stream);
+    DevBuf<int> pyrow;
+    plan_setup_symbol_rows(p.get(), G2.p, perm[1], pyrow);
+    p->sym.alloc((size_t)d->W * p->sym_rows * p->pads[2]);
+    pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, rank * ntiles, ntiles, scale, p->stream);
     LSFC_HIP(hipStreamSynchronize(p->stream));
     G2.release();
     d->S1.alloc((size_t)p->pads[0] * m * lz);

@@ -145,15 +145,16 @@ template <int R> __device__ __forceinline__ void twiddle_powers(cplx w1, cplx (&
     }
 }
 
-// Factorisation of one line.
-template <int L_, int T_, int R0_, int R1_, int R2_ = 1> struct Cfg {
+// Factorisation of one line into 2..4 stages.
+template <int L_, int T_, int R0_, int R1_, int R2_ = 1, int R3_ = 1> struct Cfg {
     static constexpr int L = L_, T = T_, E = L_ / T_;
-    static constexpr int R0 = R0_, R1 = R1_, R2 = R2_;
-    static constexpr int NS = (R2_ > 1) ? 3 : 2;
-    static_assert(R0_ * R1_ * R2_ == L_, "radices must multiply to L");
-    static_assert(E % R0_ == 0 && E % R1_ == 0 && E % R2_ == 0, "radix must divide elements per thread");
-    template <int S> static constexpr int LS() { return S == 0 ? L : (S == 1 ? L / R0 : L / (R0 * R1)); }
-    template <int S> static constexpr int R() { return S == 0 ? R0 : (S == 1 ? R1 : R2); }
+    static constexpr int R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_;
+    static constexpr int NS = 2 + (R2_ > 1 ? 1 : 0) + (R3_ > 1 ? 1 : 0);
+    static_assert(R0_ * R1_ * R2_ * R3_ == L_, "radices must multiply to L");
+    static_assert(E % R0_ == 0 && E % R1_ == 0 && E % R2_ == 0 && E % R3_ == 0, "radix must divide elements per thread");
+    static_assert(R3_ == 1 || R2_ > 1, "a 4th stage needs a 3rd");
+    template <int S> static constexpr int LS() { return S == 0 ? L : (S == 1 ? L / R0 : (S == 2 ? L / (R0 * R1) : L / (R0 * R1 * R2))); }
+    template <int S> static constexpr int R() { return S == 0 ? R0 : (S == 1 ? R1 : (S == 2 ? R2 : R3)); }
 };
 
 // In-place position touched by slot e of thread t in stage S.
@@ -254,16 +255,24 @@ __device__ __forceinline__ void fft_forward(cplx (&v)[C::E], int t, const cplx* 
     stage<C, 0, +1, PRUNE_IN ? 1 : 0>(v, t, tw);
     exchange<C, 0, 1, LL>(v, t, smem, off, xi);
     stage<C, 1, +1, 0>(v, t, tw);
-    if constexpr (C::NS == 3) {
+    if constexpr (C::NS >= 3) {
         exchange<C, 1, 2, LL>(v, t, smem, off, xi);
         stage<C, 2, +1, 0>(v, t, tw);
+    }
+    if constexpr (C::NS >= 4) {
+        exchange<C, 2, 3, LL>(v, t, smem, off, xi);
+        stage<C, 3, +1, 0>(v, t, tw);
     }
 }
 
 // storage order in slots -> natural (time) order in slots, unnormalised
 template <class C, class LL, bool PRUNE_OUT>
 __device__ __forceinline__ void fft_inverse(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
-    if constexpr (C::NS == 3) {
+    if constexpr (C::NS >= 4) {
+        stage<C, 3, -1, 0>(v, t, tw);
+        exchange<C, 3, 2, LL>(v, t, smem, off, xi);
+    }
+    if constexpr (C::NS >= 3) {
         stage<C, 2, -1, 0>(v, t, tw);
         exchange<C, 2, 1, LL>(v, t, smem, off, xi);
     }
@@ -271,22 +280,25 @@ __device__ __forceinline__ void fft_inverse(cplx (&v)[C::E], int t, const cplx* 
     exchange<C, 1, 0, LL>(v, t, smem, off, xi);
     stage<C, 0, -1, PRUNE_OUT ? 2 : 0>(v, t, tw);
 }
-
 #endif // !LSFC_FFT_HOST_EMULATION
 
 // Host mirror of the slot bookkeeping: frequency index held at storage index s.
+// After the last stage slot e = u + NB*q of thread t sits at position (t + T*u)*RL + q; in-place DIF leaves
+// frequency k = k0 + R0*(k1 + R1*(k2 + R2*k3)) at position k0*M0 + k1*M1 + k2*M2 + k3 (M_s = L / (R0..R_s)).
 template <class C> inline void perm_table(int* freq_of_storage) {
-    constexpr int RL = (C::NS == 3) ? C::R2 : C::R1;       // radix of the last stage
-    constexpr int NB = C::E / RL;
-    constexpr int M0 = C::L / C::R0;
+    const int rad[4] = { C::R0, C::R1, C::R2, C::R3 };
+    const int RL = rad[C::NS - 1];
+    const int NB = C::E / RL;
     for (int t = 0; t < C::T; ++t)
         for (int e = 0; e < C::E; ++e) {
             const int u = e % NB, q = e / NB;
-            const int pos = (t + C::T * u) * RL + q;
-            const int k0 = pos / M0, rem = pos % M0;
-            int k;
-            if (C::NS == 3) { const int k1 = rem / C::R2, k2 = rem % C::R2; k = k0 + C::R0 * (k1 + C::R1 * k2); }
-            else k = k0 + C::R0 * rem;
+            int rem = (t + C::T * u) * RL + q;
+            int k = 0, weight = 1, M = C::L;
+            for (int s = 0; s < C::NS; ++s) {
+                M /= rad[s];
+                const int ks = rem / M; rem %= M;
+                k += ks * weight; weight *= rad[s];
+            }
             freq_of_storage[t + C::T * e] = k;
         }
 }

@@ -27,7 +27,7 @@ static constexpr int XB = 8;           // x' lines per strided workgroup: 8 * 16
 template <class C, int LPW, bool SPLIT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __restrict__ out,
-            const cplx* __restrict__ tw, int64_t nlines, int logW) {
+            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, n = C::L / 2;
@@ -49,12 +49,12 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
     fft_forward<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
     if (valid) {
         // storage index s of this line goes to chunk s>>logW (one chunk per destination rank of the slab
-        // transpose; a single chunk of width L on one GPU): out[chunk][line][s & (W-1)]
+        // transpose; a single chunk of width L on one GPU): out[chunk][line][s & (W-1)], row pitch Wp >= W
         const int64_t W = (int64_t)1 << logW;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int s = t + T * e;
-            out[(int64_t)(s >> logW) * (W * nlines) + line * W + (s & (W - 1))] = v[e];
+            out[(int64_t)(s >> logW) * ((int64_t)Wp * nlines) + line * Wp + (s & (W - 1))] = v[e];
         }
     }
 }
@@ -62,7 +62,7 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
 template <class C, int LPW, bool SPLIT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alpha, double beta,
-            const cplx* __restrict__ tw, int64_t nlines, int logW) {
+            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, n = C::L / 2;
@@ -75,7 +75,7 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int s = t + T * e;
-        v[e] = in[(int64_t)(s >> logW) * (W * nlines) + lc * W + (s & (W - 1))];
+        v[e] = in[(int64_t)(s >> logW) * ((int64_t)Wp * nlines) + lc * Wp + (s & (W - 1))];
     }
     fft_inverse<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
     if (valid) {
@@ -90,9 +90,9 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
 }
 
 // A1[Lx][m][l] (natural) -> A2[XB][l][Ly][Lx/XB]
-template <class C, int LINES, bool SPLIT>
-__global__ __launch_bounds__(C::T * LINES)
-void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ) {
+template <class C, int LINES, bool SPLIT, int WPE>
+__global__ __launch_bounds__(C::T * LINES, WPE)
+void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ, int p1, int p2) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, Ly = C::L;
@@ -104,22 +104,22 @@ void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __re
     const int ntg = ngrp / TG;
     const int g = (tile % ntg) * TG + within % TG, z = (tile / ntg) * TZ + within / TG;
     const int xp = g * LINES + xi;                       // x' storage index
-    const cplx* src = a1 + xp + (int64_t)Lx * m * z;
+    const cplx* src = a1 + xp + (int64_t)p1 * m * z;
     cplx v[E];
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) v[e] = src[(int64_t)Lx * (t + T * e)];
+    for (int e = 0; e < E / 2; ++e) v[e] = src[(int64_t)p1 * (t + T * e)];
 #pragma unroll
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
     fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
     const int xb = xp / XB, xq = xp % XB;
-    cplx* dst = a2 + xq + (int64_t)XB * (z + (int64_t)l * ((int64_t)Ly * xb));
+    cplx* dst = a2 + xq + (int64_t)XB * z + (int64_t)p2 * ((int64_t)Ly * xb);
 #pragma unroll
-    for (int e = 0; e < E; ++e) dst[(int64_t)XB * l * (t + T * e)] = v[e];
+    for (int e = 0; e < E; ++e) dst[(int64_t)p2 * (t + T * e)] = v[e];
 }
 
-template <class C, int LINES, bool SPLIT>
-__global__ __launch_bounds__(C::T * LINES)
-void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ) {
+template <class C, int LINES, bool SPLIT, int WPE>
+__global__ __launch_bounds__(C::T * LINES, WPE)
+void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ, int p1, int p2) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, Ly = C::L;
@@ -132,14 +132,14 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
     const int g = (tile % ntg) * TG + within % TG, z = (tile / ntg) * TZ + within / TG;
     const int xp = g * LINES + xi;
     const int xb = xp / XB, xq = xp % XB;
-    const cplx* src = a2 + xq + (int64_t)XB * (z + (int64_t)l * ((int64_t)Ly * xb));
+    const cplx* src = a2 + xq + (int64_t)XB * z + (int64_t)p2 * ((int64_t)Ly * xb);
     cplx v[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = src[(int64_t)XB * l * (t + T * e)];
+    for (int e = 0; e < E; ++e) v[e] = src[(int64_t)p2 * (t + T * e)];
     fft_inverse<C, LL, true>(v, t, tw, smem, 0, xi);
-    cplx* dst = a1 + xp + (int64_t)Lx * m * z;
+    cplx* dst = a1 + xp + (int64_t)p1 * m * z;
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) dst[(int64_t)Lx * (t + T * e)] = v[e];
+    for (int e = 0; e < E / 2; ++e) dst[(int64_t)p1 * (t + T * e)] = v[e];
 }
 
 // In-place forward -> .* sym -> inverse along one strided axis.
@@ -149,17 +149,33 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
 // butterflies (+E complex registers; pays at E = 16 where the kernel runs at 2 waves/SIMD either way).
 // Tried and dropped (profiles/r01_experiment_*.log): LDS-only exchange barriers, non-temporal accesses, and a
 // persistent software-pipelined form of all five kernels (register pressure and spills cost more than the overlap won).
-template <class C, int LINES, bool SPLIT, bool PREFETCH>
-__global__ __launch_bounds__(C::T * LINES)
+// HALF: the workgroup transforms only 4 of the 8 interleaved lines of a tile (64 B of every 128-B line); the two
+// halves of a tile are blocks b and b+8 of a group of 16, i.e. (by the observed round-robin placement) on the SAME
+// XCD, whose L2 merges their reads and writes of the shared lines.  Halving the workgroup to 4 waves lets two (or
+// three) independent workgroups share a CU at the same register budget, so one computes while the other waits on HBM.
+template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF = false>
+__global__ __launch_bounds__(C::T * LINES, WPE)
 void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
-              int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine) {
+              int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
+              const int2* __restrict__ ytab) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
-    const int xi = threadIdx.x % LINES, t = threadIdx.x / LINES;
-    const int outer = blockIdx.x % nouter, g = blockIdx.x / nouter;
+    int xi = threadIdx.x % LINES; const int t = threadIdx.x / LINES;
+    unsigned tile = blockIdx.x;
+    if constexpr (HALF) {
+        const unsigned b = blockIdx.x;
+        tile = (b >> 4) * 8 + (b & 7);
+        xi += (int)((b >> 3) & 1) * LINES;
+    }
+    // block order -> (data row, symbol row): with a y-even symbol a row and its mirror share one symbol row and sit
+    // next to each other in block order, so the second read of that row is served by the Infinity Cache, not HBM
+    const int o = tile % nouter, g = tile / nouter;
+    int outer = o, srow = o;
+    if (ytab) { const int2 e = ytab[o]; outer = e.x; srow = e.y; }
     cplx* d = data + g * dGrp + outer * dOuter + xi;
-    const cplx* s = sym + g * sGrp + outer * sOuter + xi;
+    const cplx* s = sym + g * sGrp + srow * sOuter + xi;
+    const int li = threadIdx.x % LINES;                 // line slot inside this workgroup's LDS
     cplx v[E];
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) v[e] = d[dLine * (t + T * e)];
@@ -170,15 +186,15 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
         cplx sv[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) sv[e] = s[sLine * (t + T * e)];
-        fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
+        fft_forward<C, LL, true>(v, t, tw, smem, 0, li);
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = cmul(v[e], sv[e]);
     } else {
-        fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
+        fft_forward<C, LL, true>(v, t, tw, smem, 0, li);
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = cmul(v[e], s[sLine * (t + T * e)]);
     }
-    fft_inverse<C, LL, true>(v, t, tw, smem, 0, xi);
+    fft_inverse<C, LL, true>(v, t, tw, smem, 0, li);
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) d[dLine * (t + T * e)] = v[e];
 }
@@ -195,24 +211,24 @@ template <class C> struct Tune {
     // lines per workgroup: contiguous passes use 256-thread workgroups; strided passes
     // interleave XB lines unless that would exceed 512 threads.
     static constexpr int LPW = (256 / C::T) > 0 ? (256 / C::T) : 1;
-    static constexpr int LINES = (C::T * XB <= 512) ? XB : 512 / C::T;
+    static constexpr int LINES = (C::T * XB <= 512 || (C::E <= 8 && C::T * XB <= 1024)) ? XB : 512 / C::T;
 };
 
-template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int logW, hipStream_t st) {
+template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int logW, int Wp, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = k_xfwd<C, LPW, SPLIT>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW, Wp);
 }
-template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int logW, hipStream_t st) {
+template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int logW, int Wp, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = k_xinv<C, LPW, SPLIT>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW, Wp);
 }
 static void ytile(const PrunedTuning& tn, int L, int ngrp, int l, int& TG, int& TZ) {
     // auto (0): all groups x 1 plane, except at L >= 1024 where 32 groups x 8 planes keeps the 128-B chunks that the
@@ -221,44 +237,61 @@ static void ytile(const PrunedTuning& tn, int L, int ngrp, int l, int& TG, int& 
     TG = tn.ytile_g > 0 ? tn.ytile_g : ag; if (TG > ngrp) TG = ngrp; while (ngrp % TG) --TG;
     TZ = tn.ytile_z > 0 ? tn.ytile_z : az; if (TZ > l) TZ = l;       while (l % TZ) --TZ;
 }
-template <class C, bool SPLIT> static void yfwd_t(const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
+template <class C, bool SPLIT, int WPE> static void yfwd_t(const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
     constexpr int LINES = Tune<C>::LINES;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = k_yfwd<C, LINES, SPLIT>;
+    auto k = k_yfwd<C, LINES, SPLIT, WPE>;
     allow_lds(k, lds);
     int TG, TZ; ytile(tn, C::L, Lx / LINES, l, TG, TZ);
-    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a1, a2, tw, Lx, m, l, TG, TZ);
+    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a1, a2, tw, Lx, m, l, TG, TZ, p1, p2);
 }
-template <class C, bool SPLIT> static void yinv_t(const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
+template <class C, bool SPLIT, int WPE> static void yinv_t(const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
     constexpr int LINES = Tune<C>::LINES;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = k_yinv<C, LINES, SPLIT>;
+    auto k = k_yinv<C, LINES, SPLIT, WPE>;
     allow_lds(k, lds);
     int TG, TZ; ytile(tn, C::L, Lx / LINES, l, TG, TZ);
-    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l, TG, TZ);
+    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l, TG, TZ, p1, p2);
 }
-template <class C, bool SPLIT, bool PREFETCH> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+template <class C, bool SPLIT, bool PREFETCH, int WPE> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                                                     int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                                                    hipStream_t st) {
+                                                    const int2* ytab, hipStream_t st) {
     // dTile/sTile are strides per XB-tile of x'; a workgroup covers LINES of the XB lines of a tile.
     constexpr int LINES = Tune<C>::LINES;
     static_assert(XB % LINES == 0, "LINES must divide XB");
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = k_zfused<C, LINES, SPLIT, PREFETCH>;
+    auto k = k_zfused<C, LINES, SPLIT, PREFETCH, WPE>;
     allow_lds(k, lds);
     if (LINES == XB) {
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / XB) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           dTile, dOuter, dLine, sTile, sOuter, sLine);
+                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab);
     } else {
         // split each tile into XB/LINES sub-groups: sub-group h starts at xi offset h*LINES
         // (tile, sub-group) collapse to one group index only when tiles are XB-contiguous in xi (2D natural layout)
         LSFC_REQUIRE(dTile == XB && sTile == XB, "sub-tile groups need the natural (2D) layout");
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine);
+                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab);
     }
+}
+
+static bool occ2_for(int knob, int L) { return L == 1024 && knob > 0; }
+
+// half-tile z pass (L = 1024 in 3D tiled layout only): 4-line workgroups, sibling halves 8 blocks apart
+template <class C, bool SPLIT, bool PREFETCH, int WPE> static void zfused_half_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+                                                         int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
+                                                         const int2* ytab, hipStream_t st) {
+    constexpr int LINES = 4;
+    using LL = LdsLayout<LINES, 3, SPLIT>;
+    const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
+    auto k = k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true>;
+    allow_lds(k, lds);
+    const int64_t ntiles = (int64_t)(Lx / XB) * nouter;
+    LSFC_REQUIRE(ntiles % 8 == 0, "half-tile z pass needs a multiple of 8 tiles");
+    hipLaunchKernelGGL(k, dim3((unsigned)(2 * ntiles)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
+                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab);
 }
 
 static bool env_flag(const char* name, bool dflt) {
@@ -278,12 +311,16 @@ static bool env_flag(const char* name, bool dflt) {
     case 2048: { using C = Cfg2048; CALL; } break;                         \
     default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); }
 
+// strided passes: at L = 1024 the 8-elements-per-thread factorisation can replace the 16-element one
+#define LSFC_DISPATCH_LV(L, V, CALL)                                       \
+    if ((L) == 1024 && (V) == 1) { using C = Cfg1024S; CALL; } else { LSFC_DISPATCH_L(L, CALL) }
+
 bool pruned_length_supported(int64_t L) {
     return L == 32 || L == 64 || L == 128 || L == 256 || L == 512 || L == 1024 || L == 2048;
 }
 
-void pruned_perm(int L, int* freq_of_storage) {
-    LSFC_DISPATCH_L(L, perm_table<C>(freq_of_storage));
+void pruned_perm(int L, int variant, int* freq_of_storage) {
+    LSFC_DISPATCH_LV(L, variant, perm_table<C>(freq_of_storage));
 }
 
 PrunedTuning pruned_default_tuning() {
@@ -291,6 +328,13 @@ PrunedTuning pruned_default_tuning() {
     t.split_x = env_flag("LSFC_SPLIT_X", true);
     t.split_s = env_flag("LSFC_SPLIT_S", true);
     if (const char* v = getenv("LSFC_SPLIT_Z")) t.split_z = atoi(v);
+    if (const char* v = getenv("LSFC_PAD1")) t.pad1 = atoi(v);
+    if (const char* v = getenv("LSFC_PAD2")) t.pad2 = atoi(v);
+    if (const char* v = getenv("LSFC_Z_HALF")) t.z_half = atoi(v);
+    if (const char* v = getenv("LSFC_CFG_Y")) t.cfg_y = atoi(v);
+    if (const char* v = getenv("LSFC_CFG_Z")) t.cfg_z = atoi(v);
+    if (const char* v = getenv("LSFC_OCC2_Y")) t.occ2_y = atoi(v);
+    if (const char* v = getenv("LSFC_OCC2_Z")) t.occ2_z = atoi(v);
     if (const char* v = getenv("LSFC_SYM_PREFETCH")) t.sym_prefetch = atoi(v);
     if (const char* v = getenv("LSFC_YTILE_G")) t.ytile_g = atoi(v);
     if (const char* v = getenv("LSFC_YTILE_Z")) t.ytile_z = atoi(v);
@@ -299,35 +343,59 @@ PrunedTuning pruned_default_tuning() {
 
 static int log2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; LSFC_REQUIRE((1 << l) == v, "chunk width %d is not a power of two", v); return l; }
 
-void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, hipStream_t st) {
+void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, hipStream_t st) {
     const int logW = log2_exact(W);
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, logW, st))); }
-    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, logW, st))); }
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, logW, Wp, st))); }
+    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, logW, Wp, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, hipStream_t st) {
+void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, hipStream_t st) {
     const int logW = log2_exact(W);
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, logW, st))); }
-    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, logW, st))); }
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, st))); }
+    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
-    if (tn.split_s) { LSFC_DISPATCH_L(L, (yfwd_t<C, true>(tn, a1, a2, tw, Lx, m, l, st))); }
-    else            { LSFC_DISPATCH_L(L, (yfwd_t<C, false>(tn, a1, a2, tw, Lx, m, l, st))); }
+void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
+    // occ2: cap registers at 128 so that two 512-thread workgroups share a CU (needs the split LDS layout)
+    if (occ2_for(tn.occ2_y, L) && !tn.cfg_y) { using C = Cfg1024; yfwd_t<C, true, 4>(tn, a1, a2, tw, Lx, m, l, p1, p2, st); }
+    else if (tn.split_s) { LSFC_DISPATCH_LV(L, tn.cfg_y, (yfwd_t<C, true, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
+    else                 { LSFC_DISPATCH_LV(L, tn.cfg_y, (yfwd_t<C, false, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t st) {
-    if (tn.split_s) { LSFC_DISPATCH_L(L, (yinv_t<C, true>(tn, a2, a1, tw, Lx, m, l, st))); }
-    else            { LSFC_DISPATCH_L(L, (yinv_t<C, false>(tn, a2, a1, tw, Lx, m, l, st))); }
+void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
+    if (occ2_for(tn.occ2_y, L) && !tn.cfg_y) { using C = Cfg1024; yinv_t<C, true, 4>(tn, a2, a1, tw, Lx, m, l, p1, p2, st); }
+    else if (tn.split_s) { LSFC_DISPATCH_LV(L, tn.cfg_y, (yinv_t<C, true, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
+    else                 { LSFC_DISPATCH_LV(L, tn.cfg_y, (yinv_t<C, false, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
     LSFC_HIP(hipGetLastError());
 }
 void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
-                   int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, hipStream_t st) {
-#define LSFC_ZF(SP, PF) LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, st)))
+                   int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, const int2* ytab, hipStream_t st) {
+#define LSFC_ZF(SP, PF) LSFC_DISPATCH_LV(L, zvariant, (zfused_t<C, SP, PF, 1>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st)))
+    const int zvariant = (dLine == 8) ? tn.cfg_z : tn.cfg_y;      // 2D: the fused pass runs along y
+    // auto (-1): half-tile, split exchanges, symbol prefetch -- 6.95 -> 6.6 ms at 512^3 (profiles/r01_experiment_half_tile.log)
+    const int zh = tn.z_half >= 0 ? tn.z_half : 2;
+    if (L == 1024 && zh > 0 && !tn.cfg_z && dLine == 8 && ((int64_t)(Lx / XB) * nouter) % 8 == 0) {
+        using C = Cfg1024;
+        switch (zh) {
+        case 1: zfused_half_t<C, false, true, 2>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st); break;
+        case 2: zfused_half_t<C, true, true, 2>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st); break;
+        case 3: zfused_half_t<C, true, false, 3>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st); break;
+        default: zfused_half_t<C, false, false, 2>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st); break;
+        }
+        LSFC_HIP(hipGetLastError());
+        return;
+    }
+    if (occ2_for(tn.occ2_z, L) && !zvariant) {
+        using C = Cfg1024;
+        zfused_t<C, true, false, 4>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st);
+        LSFC_HIP(hipGetLastError());
+        return;
+    }
     // auto (-1): measured on MI355X -- at L >= 1024 (16 elements/thread, 2 waves/SIMD either way) whole-complex
     // exchanges + symbol prefetch win (7.4 -> 6.7 ms at 512^3); below, split exchanges without prefetch (more waves)
-    const bool sp = tn.split_z >= 0 ? tn.split_z != 0 : (L < 1024);
-    const bool pf = tn.sym_prefetch >= 0 ? tn.sym_prefetch != 0 : (L >= 1024);
+    const bool e16 = L >= 1024 && !zvariant;
+    const bool sp = tn.split_z >= 0 ? tn.split_z != 0 : !e16;
+    const bool pf = tn.sym_prefetch >= 0 ? tn.sym_prefetch != 0 : e16;
     if (sp) { if (pf) { LSFC_ZF(true, true); } else { LSFC_ZF(true, false); } }
     else    { if (pf) { LSFC_ZF(false, true); } else { LSFC_ZF(false, false); } }
 #undef LSFC_ZF

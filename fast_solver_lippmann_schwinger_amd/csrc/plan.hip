@@ -131,6 +131,38 @@ void plan_finish_literal(lsfc_plan* p, const cplx* Gd, bool centred) {
     LSFC_HIP(hipStreamSynchronize(p->stream));
 }
 
+void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>& perm_y, DevBuf<int>& pyrow) {
+    const int Ly = p->pads[1];
+    // The Green's symbols of the reference are even in every axis.  When the reduced symbol handed to us is even in
+    // y (checked numerically: the literal-symbol constructors accept arbitrary data) only the rows with ky <= Ly/2
+    // are stored, and each row is scheduled right next to its mirror: the second read of the shared symbol row is
+    // served on-die by the Infinity Cache, which removes ~1/8 of the apply's HBM traffic.
+    bool even = false;
+    const char* env = getenv("LSFC_SYM_EVEN_Y");
+    if (!(env && env[0] == '0') && p->ndim == 3 && Ly >= 4) even = pw_ymirror_deviation(G2, p->pads, p->stream) < 1e-13;
+    std::vector<int> inv((size_t)Ly), rowky;
+    for (int s = 0; s < Ly; ++s) inv[perm_y[s]] = s;
+    std::vector<int2> tab;
+    if (even) {
+        std::vector<int> rowof((size_t)Ly, -1);
+        for (int s = 0; s < Ly; ++s) if (perm_y[s] <= Ly / 2) { rowof[s] = (int)rowky.size(); rowky.push_back(perm_y[s]); }
+        for (int s = 0; s < Ly; ++s) {
+            if (rowof[s] < 0) continue;
+            tab.push_back(make_int2(s, rowof[s]));
+            const int mirror = inv[(Ly - perm_y[s]) % Ly];
+            if (mirror != s) tab.push_back(make_int2(mirror, rowof[s]));
+        }
+    } else {
+        for (int s = 0; s < Ly; ++s) { rowky.push_back(perm_y[s]); tab.push_back(make_int2(s, s)); }
+    }
+    LSFC_REQUIRE((int)tab.size() == Ly, "internal: row table has %d entries for %d rows", (int)tab.size(), Ly);
+    p->sym_rows = (int)rowky.size();
+    p->ytab.alloc(tab.size());
+    LSFC_HIP(hipMemcpy(p->ytab.p, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice));
+    pyrow.alloc(rowky.size());
+    LSFC_HIP(hipMemcpy(pyrow.p, rowky.data(), rowky.size() * sizeof(int), hipMemcpyHostToDevice));
+}
+
 void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
     for (int d = 0; d < 3; ++d) { p->pads[d] = (d < p->ndim) ? 2 * p->dims[d] : 1; p->crop[d] = 0; }
     const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
@@ -140,17 +172,32 @@ void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
         DevBuf<int> dperm[3];
         for (int d = 0; d < p->ndim; ++d) {
             perm[d].resize((size_t)p->pads[d]);
-            pruned_perm(p->pads[d], perm[d].data());
+            // x passes always use the default factorisation; the y / z storage orders follow the strided passes' variant
+            pruned_perm(p->pads[d], d == 1 ? p->tuning.cfg_y : (d == 2 ? p->tuning.cfg_z : 0), perm[d].data());
             dperm[d].alloc(perm[d].size());
             LSFC_HIP(hipMemcpy(dperm[d].p, perm[d].data(), perm[d].size() * sizeof(int), hipMemcpyHostToDevice));
             make_twiddles(p, d, p->pads[d]);
         }
-        p->sym.alloc((size_t)total);
-        pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, 0, p->pads[0] / 8, scale, p->stream);
+        if (p->ndim == 3) {
+            DevBuf<int> pyrow;
+            plan_setup_symbol_rows(p, G2.p, perm[1], pyrow);
+            p->sym.alloc((size_t)p->pads[0] * p->sym_rows * p->pads[2]);
+            pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, 0, p->pads[0] / 8, scale, p->stream);
+        } else {
+            p->sym.alloc((size_t)total);
+            pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, p->pads[1], 0, p->pads[0] / 8, scale, p->stream);
+        }
         LSFC_HIP(hipStreamSynchronize(p->stream));
         G2.release();
-        p->A1.alloc((size_t)p->pads[0] * p->dims[1] * p->dims[2]);
-        if (p->ndim == 3) p->A2.alloc((size_t)p->pads[0] * p->pads[1] * p->dims[2]);
+        // row padding of the work arrays (auto: at 2m >= 1024 the 16-KB / 64-KB power-of-two row strides of the y passes
+        // are broken up by +40 / +72 elements: yfwd 2.86 -> 2.59 ms, yinv 2.92 -> 2.57 ms at 512^3; neutral or worse below)
+        const bool big = p->ndim == 3 && p->pads[1] >= 1024;
+        const int pad1 = p->tuning.pad1 >= 0 ? p->tuning.pad1 : (big ? 40 : 0);
+        const int pad2 = p->tuning.pad2 >= 0 ? p->tuning.pad2 : (big ? 72 : 0);
+        p->pitch1 = p->pads[0] + ((p->ndim == 3) ? pad1 / 8 * 8 : 0);
+        p->pitch2 = 8 * p->dims[2] + pad2 / 8 * 8;
+        p->A1.alloc((size_t)p->pitch1 * p->dims[1] * p->dims[2]);
+        if (p->ndim == 3) p->A2.alloc((size_t)p->pitch2 * p->pads[1] * (p->pads[0] / 8));
         p->pipeline = lsfc_plan::PRUNED;
     } else {
         pw_scale(G2.p, scale, total, p->stream);
@@ -201,16 +248,17 @@ void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
         const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
         const int m = p->dims[1], l = p->dims[2];
         const int64_t nlines = (int64_t)m * l;
-        pruned_xfwd(Lx, p->tuning, x, nu, p->A1.p, p->tw[0].p, nlines, Lx, st);
+        pruned_xfwd(Lx, p->tuning, x, nu, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, st);
         if (p->ndim == 3) {
-            pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, st);
+            const int p1 = p->pitch1, p2 = p->pitch2;
+            pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, p1, p2, st);
             pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
-                          (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * Ly, (int64_t)8 * Lz, 8, st);
-            pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, st);
+                          (int64_t)p2 * Ly, (int64_t)p2, 8, (int64_t)8 * Lz * p->sym_rows, (int64_t)8 * Lz, 8, p->ytab.p, st);
+            pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p1, p2, st);
         } else {
-            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, Lx, 8, 0, Lx, st);
+            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, st);
         }
-        pruned_xinv(Lx, p->tuning, p->A1.p, x, y, alpha, beta, p->tw[0].p, nlines, Lx, st);
+        pruned_xinv(Lx, p->tuning, p->A1.p, x, y, alpha, beta, p->tw[0].p, nlines, Lx, p->pitch1, st);
     } else {
         const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
         pw_embed(x, nu, p->W.p, p->dims, p->pads, st);
@@ -477,6 +525,9 @@ int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value) {
         if (k == "split_x") plan->tuning.split_x = value != 0;
         else if (k == "split_s") plan->tuning.split_s = value != 0;
         else if (k == "split_z") plan->tuning.split_z = value;
+        else if (k == "z_half") plan->tuning.z_half = value;
+        else if (k == "occ2_y") plan->tuning.occ2_y = value;
+        else if (k == "occ2_z") plan->tuning.occ2_z = value;
         else if (k == "sym_prefetch") plan->tuning.sym_prefetch = value;
         else if (k == "ytile_g") plan->tuning.ytile_g = value;
         else if (k == "ytile_z") plan->tuning.ytile_z = value;
@@ -522,16 +573,16 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
             const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
             const int m = p->dims[1], l = p->dims[2];
             const int64_t nlines = (int64_t)m * l;
-            stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, [=] { pruned_xfwd(Lx, p->tuning, x, p->nu.p, p->A1.p, p->tw[0].p, nlines, Lx, st); }});
+            stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, [=] { pruned_xfwd(Lx, p->tuning, x, p->nu.p, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, st); }});
             if (p->ndim == 3) {
-                stages.push_back({"yfwd", (2 + 4) * N * C, [=] { pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, st); }});
+                stages.push_back({"yfwd", (2 + 4) * N * C, [=] { pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, p->pitch1, p->pitch2, st); }});
                 stages.push_back({"zfused", (4 + 8 + 4) * N * C, [=] { pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
-                                  (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * Ly, (int64_t)8 * Lz, 8, st); }});
-                stages.push_back({"yinv", (4 + 2) * N * C, [=] { pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, st); }});
+                                  (int64_t)p->pitch2 * Ly, (int64_t)p->pitch2, 8, (int64_t)8 * Lz * p->sym_rows, (int64_t)8 * Lz, 8, p->ytab.p, st); }});
+                stages.push_back({"yinv", (4 + 2) * N * C, [=] { pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p->pitch1, p->pitch2, st); }});
             } else {
-                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, Lx, 8, 0, Lx, st); }});
+                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, st); }});
             }
-            stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, Lx, st); }});
+            stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, Lx, p->pitch1, st); }});
         } else {
             const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
             const double P = (double)total;

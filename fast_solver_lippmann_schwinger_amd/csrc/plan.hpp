@@ -81,6 +81,10 @@ struct lsfc_plan {
     lsfc::PrunedTuning tuning;
     lsfc::DevBuf<lsfc::cplx> tw[3];
     lsfc::DevBuf<lsfc::cplx> A1, A2;
+    // y-even symbol: only rows with ky <= Ly/2 are stored (sym_rows of them); ytab[o] = (data row, symbol row) in block order
+    int sym_rows = 0;
+    lsfc::DevBuf<int2> ytab;
+    int pitch1 = 0, pitch2 = 0;      // row pitch of A1 (>= Lx) and of one storage-y row of an A2 tile (>= 8*l)
 
     // rocFFT pipelines
     std::unique_ptr<lsfc::RocFft> fwd, inv;
@@ -128,6 +132,10 @@ void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
 void dist_allreduce_sum(lsfc_plan* p, cplx* dev, int count);           // no-op unless a real multi-rank plan
 void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y,
                          std::function<void(const char*, double, std::function<void()>)> add);
+
+// symbol rows / block order of the z pass for a (possibly) y-even symbol: fills p->sym_rows, p->ytab, returns the
+// device table of the y frequency of every stored row (plan.hip)
+void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>& perm_y, DevBuf<int>& pyrow);
 
 // GMRES (gmres.hip)
 void gmres_run(lsfc_plan* p, cplx* x_dev, const cplx* b_dev, const lsfc_gmres_opts* opts, double* resnorm, int64_t cap,

@@ -4,6 +4,8 @@
 // reductions with a fixed-order second stage (bitwise reproducible, no float atomics).
 #include "common.hpp"
 #include "pointwise.hpp"
+#include <algorithm>
+#include <vector>
 
 namespace lsfc {
 
@@ -98,20 +100,58 @@ __global__ void k_wrap_crop(const cplx* __restrict__ src, cplx* __restrict__ dst
 
 // Natural FFT-order symbol G2[Lx][Ly][Lz] -> storage-order, tile-interleaved layout of the
 // pruned pipeline.  3D: out[xi + 8*(sz + Lz*(sy + Ly*xb))];  2D (Lz==1): out[sx + Lx*sy].
+// 3D: `rows` symbol rows per tile; pyrow[r] = y frequency of row r (rows == Ly: every storage row; rows == Ly/2+1:
+// only the rows with ky <= Ly/2 of a y-even symbol, shared by the mirror rows).
 __global__ void k_permute_symbol(const cplx* __restrict__ G2, cplx* __restrict__ out, const int* __restrict__ px,
-                                 const int* __restrict__ py, const int* __restrict__ pz, int Lx, int Ly, int Lz, int xb0, int ntiles, double scale) {
-    const int64_t total = (Lz > 1) ? (int64_t)8 * Lz * Ly * ntiles : (int64_t)Lx * Ly;
+                                 const int* __restrict__ pyrow, const int* __restrict__ pz, int Lx, int Ly, int Lz, int rows,
+                                 int xb0, int ntiles, double scale) {
+    const int64_t total = (Lz > 1) ? (int64_t)8 * Lz * rows * ntiles : (int64_t)Lx * Ly;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         int sx, sy, sz;
         if (Lz > 1) {
             const int xi = (int)(idx % 8); int64_t r = idx / 8;
-            sz = (int)(r % Lz); r /= Lz; sy = (int)(r % Ly); const int xb = (int)(r / Ly);
+            sz = (int)(r % Lz); r /= Lz; sy = (int)(r % rows); const int xb = (int)(r / rows);
             sx = (xb0 + xb) * 8 + xi;
         } else { sx = (int)(idx % Lx); sy = (int)(idx / Lx); sz = 0; }
-        const int kx = px[sx], ky = py[sy], kz = (Lz > 1) ? pz[sz] : 0;
+        const int kx = px[sx], ky = pyrow[sy], kz = (Lz > 1) ? pz[sz] : 0;
         const cplx v = G2[kx + (int64_t)Lx * (ky + (int64_t)Ly * kz)];
         out[idx] = make_double2(scale * v.x, scale * v.y);
     }
+}
+
+// partial[2b] = max |G[..ky..] - G[..(Ly-ky)..]|, partial[2b+1] = max |G| over the slice of block b
+__global__ void k_ymirror_dev(const cplx* __restrict__ G, double* __restrict__ partial, int Lx, int Ly, int Lz) {
+    __shared__ double sh[2][4];
+    const int64_t total = (int64_t)Lx * Ly * Lz;
+    double dmax = 0.0, amax = 0.0;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % Lx); const int64_t r = idx / Lx; const int j = (int)(r % Ly); const int k = (int)(r / Ly);
+        const cplx a = G[idx], b = G[i + (int64_t)Lx * (((Ly - j) % Ly) + (int64_t)Ly * k)];
+        dmax = fmax(dmax, fmax(fabs(a.x - b.x), fabs(a.y - b.y)));
+        amax = fmax(amax, fmax(fabs(a.x), fabs(a.y)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { dmax = fmax(dmax, __shfl_down(dmax, off, 64)); amax = fmax(amax, __shfl_down(amax, off, 64)); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wave] = dmax; sh[1][wave] = amax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { dmax = fmax(dmax, sh[0][w]); amax = fmax(amax, sh[1][w]); }
+        partial[2 * blockIdx.x] = dmax; partial[2 * blockIdx.x + 1] = amax;
+    }
+}
+double pw_ymirror_deviation(const cplx* G, const int L[3], hipStream_t st) {
+    const int blocks = 1024;
+    DevBuf<double> part; part.alloc(2 * blocks);
+    hipLaunchKernelGGL(k_ymirror_dev, dim3(blocks), dim3(256), 0, st, G, part.p, L[0], L[1], L[2]);
+    LSFC_HIP(hipGetLastError());
+    std::vector<double> h(2 * blocks);
+    LSFC_HIP(hipMemcpyAsync(h.data(), part.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    LSFC_HIP(hipStreamSynchronize(st));
+    double d = 0, a = 0;
+    for (int b = 0; b < blocks; ++b) { d = std::max(d, h[2 * b]); a = std::max(a, h[2 * b + 1]); }
+    if (!(d == d) || !(a == a)) return 1.0;                       // NaN symbol (unpatched singular omega): never treat as even
+    return a > 0 ? d / a : 0.0;
 }
 
 __global__ void k_scale(cplx* __restrict__ a, double s, int64_t total) {
@@ -130,9 +170,9 @@ void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], do
     hipLaunchKernelGGL(k_wrap_crop, dim3(grid_for(total)), dim3(256), 0, st, src, dst, p[0], p[1], p[2], q[0], q[1], q[2], scale);
     LSFC_HIP(hipGetLastError());
 }
-void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* py, const int* pz, const int L[3], int xb0, int ntiles, double scale, hipStream_t st) {
-    const int64_t total = (L[2] > 1) ? (int64_t)8 * L[2] * L[1] * ntiles : (int64_t)L[0] * L[1];
-    hipLaunchKernelGGL(k_permute_symbol, dim3(grid_for(total)), dim3(256), 0, st, G2, out, px, py, pz, L[0], L[1], L[2], xb0, ntiles, scale);
+void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int xb0, int ntiles, double scale, hipStream_t st) {
+    const int64_t total = (L[2] > 1) ? (int64_t)8 * L[2] * rows * ntiles : (int64_t)L[0] * L[1];
+    hipLaunchKernelGGL(k_permute_symbol, dim3(grid_for(total)), dim3(256), 0, st, G2, out, px, pyrow, pz, L[0], L[1], L[2], rows, xb0, ntiles, scale);
     LSFC_HIP(hipGetLastError());
 }
 void pw_scale(cplx* a, double s, int64_t total, hipStream_t st) {

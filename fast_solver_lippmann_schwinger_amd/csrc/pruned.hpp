@@ -9,6 +9,10 @@ struct PrunedTuning {
     bool split_s = true;   // strided y passes
     int split_z = -1;      // fused z pass: 1 split, 0 whole complex, -1 auto (by line length)
     int sym_prefetch = -1; // z pass: load the symbol before the forward transform; -1 auto
+    int pad1 = -1, pad2 = -1;        // row padding (elements, multiples of 8) of the A1 rows / A2 tile rows, read at plan creation
+    int cfg_y = 0, cfg_z = 0;       // factorisation variant of the y / z passes; fixed at plan creation (defines the storage order)
+    int z_half = -1;                // L = 1024 z pass: half-tile 4-wave workgroups (1: full+prefetch, 2: split+prefetch, 3: split, 3 WG/CU, 4: full)
+    int occ2_y = 0, occ2_z = 0;     // L = 1024 only: 128-register builds of the y / z passes (two workgroups per CU)
     int ytile_g = 0, ytile_z = 0;   // y passes: block-order tile (x'-groups x z planes); 0 = auto
 };
 
@@ -16,15 +20,18 @@ bool pruned_length_supported(int64_t L);
 // W = chunk width of the x'-storage axis in the xfwd output / xinv input: out[s / W][line][s % W] (W = L on one GPU;
 // W = L / nranks packs the slab transpose for free).
 // freq_of_storage[s] = frequency index held at storage index s after the forward pass of length L
-void pruned_perm(int L, int* freq_of_storage);
+// variant: factorisation used by the strided passes along that axis (0 default; 1 at L = 1024: 8 elements per thread)
+void pruned_perm(int L, int variant, int* freq_of_storage);
 PrunedTuning pruned_default_tuning();
 
-void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, hipStream_t);
+void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, hipStream_t);
 void pruned_xinv(int L, const PrunedTuning&, const cplx* in, const cplx* xorig, cplx* y, double alpha, double beta,
-                 const cplx* tw, int64_t nlines, int W, hipStream_t);
-void pruned_yfwd(int L, const PrunedTuning&, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, hipStream_t);
-void pruned_yinv(int L, const PrunedTuning&, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, hipStream_t);
+                 const cplx* tw, int64_t nlines, int W, int Wp, hipStream_t);
+// p1: row pitch of A1 (>= Lx), p2: pitch of one storage-y row of an A2 tile (>= 8*l); both multiples of 8 elements
+void pruned_yfwd(int L, const PrunedTuning&, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);
+void pruned_yinv(int L, const PrunedTuning&, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);
 void pruned_zfused(int L, const PrunedTuning&, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
-                   int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, hipStream_t);
+                   int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
+                   const int2* ytab /* block order -> (data row, symbol row); NULL: identity */, hipStream_t);
 
 } // namespace lsfc

@@ -67,7 +67,8 @@ template <class C, class LL> static double run_cfg(const char* name, bool prune)
     if (prune) emu_stage<C, 0, +1, 1>(regs, nlines, tw.data()); else emu_stage<C, 0, +1, 0>(regs, nlines, tw.data());
     emu_exchange<C, LL, 0, 1>(regs, smem, nlines, 0);
     emu_stage<C, 1, +1, 0>(regs, nlines, tw.data());
-    if (C::NS == 3) { emu_exchange<C, LL, 1, 2>(regs, smem, nlines, 0); emu_stage<C, (C::NS == 3 ? 2 : 1), +1, 0>(regs, nlines, tw.data()); }
+    if constexpr (C::NS >= 3) { emu_exchange<C, LL, 1, 2>(regs, smem, nlines, 0); emu_stage<C, 2, +1, 0>(regs, nlines, tw.data()); }
+    if constexpr (C::NS >= 4) { emu_exchange<C, LL, 2, 3>(regs, smem, nlines, 0); emu_stage<C, 3, +1, 0>(regs, nlines, tw.data()); }
     // compare with naive DFT through perm_table
     std::vector<int> perm(L); perm_table<C>(perm.data());
     std::vector<char> seen(L, 0); for (int s = 0; s < L; ++s) { if (perm[s] < 0 || perm[s] >= L || seen[perm[s]]) { printf("%s: perm not a bijection\n", name); return 1; } seen[perm[s]] = 1; }
@@ -82,7 +83,8 @@ template <class C, class LL> static double run_cfg(const char* name, bool prune)
     }
     double fwd_err = (double)sqrtl(err / nrm);
     // inverse
-    if (C::NS == 3) { emu_stage<C, (C::NS == 3 ? 2 : 1), -1, 0>(regs, nlines, tw.data()); emu_exchange<C, LL, (C::NS == 3 ? 2 : 1), 1>(regs, smem, nlines, 0); }
+    if constexpr (C::NS >= 4) { emu_stage<C, 3, -1, 0>(regs, nlines, tw.data()); emu_exchange<C, LL, 3, 2>(regs, smem, nlines, 0); }
+    if constexpr (C::NS >= 3) { emu_stage<C, 2, -1, 0>(regs, nlines, tw.data()); emu_exchange<C, LL, 2, 1>(regs, smem, nlines, 0); }
     emu_stage<C, 1, -1, 0>(regs, nlines, tw.data());
     emu_exchange<C, LL, 1, 0>(regs, smem, nlines, 0);
     if (prune) emu_stage<C, 0, -1, 2>(regs, nlines, tw.data()); else emu_stage<C, 0, -1, 0>(regs, nlines, tw.data());
@@ -103,7 +105,7 @@ int main() {
     worst = fmax(worst, run_cfg<CFG, LdsLayout<1, 3, false>>(#CFG " contig full", false)); \
     worst = fmax(worst, run_cfg<CFG, LdsLayout<8, 3, true>>(#CFG " strided split", true)); \
     worst = fmax(worst, run_cfg<CFG, LdsLayout<8, 3, false>>(#CFG " strided full", true)); } while (0)
-    RUN(Cfg32); RUN(Cfg64); RUN(Cfg128); RUN(Cfg256); RUN(Cfg512); RUN(Cfg1024); RUN(Cfg2048);
+    RUN(Cfg32); RUN(Cfg64); RUN(Cfg128); RUN(Cfg256); RUN(Cfg512); RUN(Cfg1024); RUN(Cfg2048); RUN(Cfg1024S);
     printf("worst=%.3e\n", worst);
     return worst < 1e-13 ? 0 : 1;
 }
