@@ -90,7 +90,7 @@ void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
     LSFC_REQUIRE(!d->sim, "simulated ranks are driven through lsfc_dist_sim_apply");
     hipStream_t st = p->stream;
     phase1(p, x, use_nu, st);
-    if (d->nranks == 1) {
+    if (d->nranks == 1 && !d->force_overlap) {
         for (int c = 0; c < d->K; ++c) { exchange(p, c, false, st); phase2(p, c, st); exchange(p, c, true, st); }
         phase3(p, x, y, alpha, beta, st);
         return;
@@ -170,10 +170,12 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     // pipeline chunks: up to 4, each at least one 8-wide tile (LSFC_DIST_CHUNKS overrides; 1 disables the overlap)
     int K = 4;
     if (const char* v = getenv("LSFC_DIST_CHUNKS")) K = atoi(v);
-    if (nranks == 1 && !sim && !getenv("LSFC_DIST_CHUNKS")) K = 1;
+    if (nranks == 1 && !sim && !getenv("LSFC_DIST_CHUNKS") && !getenv("LSFC_DIST_FORCE_OVERLAP")) K = 1;
     if (K < 1) K = 1;
     while (K > 1 && (d->W % K != 0 || (d->W / K) % 8 != 0)) --K;
     d->K = K; d->Wc = d->W / K;
+    // LSFC_DIST_FORCE_OVERLAP=1: run the three-stream pipeline even with one rank (tests of the event logic)
+    d->force_overlap = getenv("LSFC_DIST_FORCE_OVERLAP") && getenv("LSFC_DIST_FORCE_OVERLAP")[0] == '1';
     if (!sim && nranks > 1) {
         LSFC_REQUIRE(id, "NULL unique id");
         ncclUniqueId uid; static_assert(sizeof(uid) == LSFC_UNIQUE_ID_BYTES, "unique id size");
@@ -183,6 +185,8 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
         d->comm = comm;
         LSFC_NCCL(ncclCommSplit(comm, 0, rank, &comm2, nullptr));
         d->comm2 = comm2;
+    }
+    if (!sim && (nranks > 1 || d->force_overlap)) {
         LSFC_HIP(hipStreamCreateWithFlags(&d->cs1, hipStreamNonBlocking));
         LSFC_HIP(hipStreamCreateWithFlags(&d->cs2, hipStreamNonBlocking));
         LSFC_HIP(hipEventCreateWithFlags(&d->ev_p1, hipEventDisableTiming));
