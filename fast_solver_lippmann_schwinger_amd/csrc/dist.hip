@@ -47,8 +47,9 @@ static void phase2_yfwd(lsfc_plan* p, int c, hipStream_t st) {
 static void phase2_zfused(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
     const int Ly = p->pads[1], Lz = p->pads[2], l = p->dims[2];
-    pruned_zfused(Lz, p->tuning, p->A2.p + (int64_t)c * d->Wc * Ly * l, p->sym.p + (int64_t)c * d->Wc * p->sym_rows * Lz, p->tw[2].p, d->Wc, Ly,
-                  (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * Lz * p->sym_rows, (int64_t)8 * Lz, 8, p->ytab.p, st);
+    pruned_zfused(Lz, p->tuning, p->A2.p + (int64_t)c * d->Wc * Ly * l, p->sym.p + (int64_t)c * d->Wc * p->sym_rows * p->sym_hz, p->tw[2].p, d->Wc, Ly,
+                  (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p,
+                  p->zmirror.p, st);
 }
 static void phase2_yinv(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
@@ -212,9 +213,9 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     const int ntiles = d->W / 8;
     const double scale = 1.0 / ((double)p->pads[0] * p->pads[1] * p->pads[2]);
     DevBuf<int> pyrow;
-    plan_setup_symbol_rows(p.get(), G2.p, perm[1], pyrow);
-    p->sym.alloc((size_t)d->W * p->sym_rows * p->pads[2]);
-    pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, rank * ntiles, ntiles, scale, p->stream);
+    plan_setup_symbol_rows(p.get(), G2.p, perm[1], perm[2], pyrow);
+    p->sym.alloc((size_t)d->W * p->sym_rows * p->sym_hz);
+    pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, p->sym_hz, rank * ntiles, ntiles, scale, p->stream);
     LSFC_HIP(hipStreamSynchronize(p->stream));
     G2.release();
     d->S1.alloc((size_t)p->pads[0] * m * lz);

@@ -153,11 +153,15 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
 // halves of a tile are blocks b and b+8 of a group of 16, i.e. (by the observed round-robin placement) on the SAME
 // XCD, whose L2 merges their reads and writes of the shared lines.  Halving the workgroup to 4 waves lets two (or
 // three) independent workgroups share a CU at the same register budget, so one computes while the other waits on HBM.
-template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF = false>
+// ZE (z-even symbol): a symbol line stores only the entries with frequency kz <= L/2 -- L/2 of them in storage order
+// (exactly the slots e < E/2 of every thread) plus the kz = L/2 entry at index L/2.  Each thread loads its E/2
+// values; the mirror values (kz -> L - kz) of its slots e >= E/2 are held by other threads of the same line and are
+// fetched through LDS (zm[s - L/2] = storage index of the partner).  Halves the symbol bytes of the pass again.
+template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF = false, bool ZE = false>
 __global__ __launch_bounds__(C::T * LINES, WPE)
 void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
               int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
-              const int2* __restrict__ ytab) {
+              const int2* __restrict__ ytab, const int* __restrict__ zm) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -181,7 +185,34 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
     for (int e = 0; e < E / 2; ++e) v[e] = d[dLine * (t + T * e)];
 #pragma unroll
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
-    if constexpr (PREFETCH) {
+    if constexpr (ZE) {
+        constexpr int H = E / 2;
+        int part[H];
+#pragma unroll
+        for (int e = 0; e < H; ++e) part[e] = zm[t + T * e];
+        cplx sv[H];
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int e = 0; e < H; ++e) sv[e] = s[sLine * (t + T * e)];
+        }
+        fft_forward<C, LL, true>(v, t, tw, smem, 0, li);
+        if constexpr (!PREFETCH) {
+#pragma unroll
+            for (int e = 0; e < H; ++e) sv[e] = s[sLine * (t + T * e)];
+        }
+        // stage this line's stored half in LDS (the exchange buffer is free between the two transforms)
+        cplx* stage = reinterpret_cast<cplx*>(smem);
+#pragma unroll
+        for (int e = 0; e < H; ++e) stage[(t + T * e) * LINES + li] = sv[e];
+        if (t == 0) stage[(C::L / 2) * LINES + li] = s[sLine * (C::L / 2)];
+        LSFC_BARRIER();
+#pragma unroll
+        for (int e = 0; e < H; ++e) {
+            v[e] = cmul(v[e], sv[e]);
+            v[e + H] = cmul(v[e + H], stage[part[e] * LINES + li]);
+        }
+        LSFC_BARRIER();
+    } else if constexpr (PREFETCH) {
         // issue the symbol loads before the forward transform: their HBM latency hides behind its butterflies
         cplx sv[E];
 #pragma unroll
@@ -255,43 +286,43 @@ template <class C, bool SPLIT, int WPE> static void yinv_t(const PrunedTuning& t
     int TG, TZ; ytile(tn, C::L, Lx / LINES, l, TG, TZ);
     hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l, TG, TZ, p1, p2);
 }
-template <class C, bool SPLIT, bool PREFETCH, int WPE> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                                                     int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                                                    const int2* ytab, hipStream_t st) {
+                                                    const int2* ytab, const int* zm, hipStream_t st) {
     // dTile/sTile are strides per XB-tile of x'; a workgroup covers LINES of the XB lines of a tile.
     constexpr int LINES = Tune<C>::LINES;
     static_assert(XB % LINES == 0, "LINES must divide XB");
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = k_zfused<C, LINES, SPLIT, PREFETCH, WPE>;
+    auto k = k_zfused<C, LINES, SPLIT, PREFETCH, WPE, false, ZE>;
     allow_lds(k, lds);
     if (LINES == XB) {
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / XB) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab);
+                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm);
     } else {
         // split each tile into XB/LINES sub-groups: sub-group h starts at xi offset h*LINES
         // (tile, sub-group) collapse to one group index only when tiles are XB-contiguous in xi (2D natural layout)
         LSFC_REQUIRE(dTile == XB && sTile == XB, "sub-tile groups need the natural (2D) layout");
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab);
+                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab, zm);
     }
 }
 
 static bool occ2_for(int knob, int L) { return L == 1024 && knob > 0; }
 
 // half-tile z pass (L = 1024 in 3D tiled layout only): 4-line workgroups, sibling halves 8 blocks apart
-template <class C, bool SPLIT, bool PREFETCH, int WPE> static void zfused_half_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static void zfused_half_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                                                          int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                                                         const int2* ytab, hipStream_t st) {
+                                                         const int2* ytab, const int* zm, hipStream_t st) {
     constexpr int LINES = 4;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true>;
+    auto k = k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true, ZE>;
     allow_lds(k, lds);
     const int64_t ntiles = (int64_t)(Lx / XB) * nouter;
     LSFC_REQUIRE(ntiles % 8 == 0, "half-tile z pass needs a multiple of 8 tiles");
     hipLaunchKernelGGL(k, dim3((unsigned)(2 * ntiles)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab);
+                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm);
 }
 
 static bool env_flag(const char* name, bool dflt) {
@@ -369,25 +400,32 @@ void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const 
     LSFC_HIP(hipGetLastError());
 }
 void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
-                   int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, const int2* ytab, hipStream_t st) {
-#define LSFC_ZF(SP, PF) LSFC_DISPATCH_LV(L, zvariant, (zfused_t<C, SP, PF, 1>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st)))
+                   int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, const int2* ytab,
+                   const int* zm, hipStream_t st) {
+#define LSFC_ZF(SP, PF) do { if (zm) { LSFC_DISPATCH_LV(L, zvariant, (zfused_t<C, SP, PF, 1, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st))); } \
+                             else    { LSFC_DISPATCH_LV(L, zvariant, (zfused_t<C, SP, PF, 1, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st))); } } while (0)
     const int zvariant = (dLine == 8) ? tn.cfg_z : tn.cfg_y;      // 2D: the fused pass runs along y
     // auto (-1): half-tile, split exchanges, symbol prefetch -- 6.95 -> 6.6 ms at 512^3 (profiles/r01_experiment_half_tile.log)
-    const int zh = tn.z_half >= 0 ? tn.z_half : 2;
+    // with the z-even half symbol the full-tile form wins (6.05 ms, profiles/r01_experiment_even_z.log)
+    const int zh = tn.z_half >= 0 ? tn.z_half : (zm ? 0 : 2);
     if (L == 1024 && zh > 0 && !tn.cfg_z && dLine == 8 && ((int64_t)(Lx / XB) * nouter) % 8 == 0) {
         using C = Cfg1024;
+#define LSFC_ZH(SP, PF, W) do { if (zm) zfused_half_t<C, SP, PF, W, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st); \
+                                else zfused_half_t<C, SP, PF, W, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st); } while (0)
         switch (zh) {
-        case 1: zfused_half_t<C, false, true, 2>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st); break;
-        case 2: zfused_half_t<C, true, true, 2>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st); break;
-        case 3: zfused_half_t<C, true, false, 3>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st); break;
-        default: zfused_half_t<C, false, false, 2>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st); break;
+        case 1: LSFC_ZH(false, true, 2); break;
+        case 2: LSFC_ZH(true, true, 2); break;
+        case 3: LSFC_ZH(true, false, 3); break;
+        default: LSFC_ZH(false, false, 2); break;
         }
+#undef LSFC_ZH
         LSFC_HIP(hipGetLastError());
         return;
     }
     if (occ2_for(tn.occ2_z, L) && !zvariant) {
         using C = Cfg1024;
-        zfused_t<C, true, false, 4>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, st);
+        LSFC_REQUIRE(!zm, "occ2_z: not available with a z-even symbol");
+        zfused_t<C, true, false, 4>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st);
         LSFC_HIP(hipGetLastError());
         return;
     }

@@ -131,15 +131,15 @@ void plan_finish_literal(lsfc_plan* p, const cplx* Gd, bool centred) {
     LSFC_HIP(hipStreamSynchronize(p->stream));
 }
 
-void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>& perm_y, DevBuf<int>& pyrow) {
-    const int Ly = p->pads[1];
+void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>& perm_y, const std::vector<int>& perm_z, DevBuf<int>& pyrow) {
+    const int Ly = p->pads[1], Lz = p->pads[2];
     // The Green's symbols of the reference are even in every axis.  When the reduced symbol handed to us is even in
     // y (checked numerically: the literal-symbol constructors accept arbitrary data) only the rows with ky <= Ly/2
     // are stored, and each row is scheduled right next to its mirror: the second read of the shared symbol row is
     // served on-die by the Infinity Cache, which removes ~1/8 of the apply's HBM traffic.
     bool even = false;
     const char* env = getenv("LSFC_SYM_EVEN_Y");
-    if (!(env && env[0] == '0') && p->ndim == 3 && Ly >= 4) even = pw_ymirror_deviation(G2, p->pads, p->stream) < 1e-13;
+    if (!(env && env[0] == '0') && p->ndim == 3 && Ly >= 4) even = pw_mirror_deviation(G2, p->pads, 1, p->stream) < 1e-13;
     std::vector<int> inv((size_t)Ly), rowky;
     for (int s = 0; s < Ly; ++s) inv[perm_y[s]] = s;
     std::vector<int2> tab;
@@ -161,6 +161,31 @@ void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>
     LSFC_HIP(hipMemcpy(p->ytab.p, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice));
     pyrow.alloc(rowky.size());
     LSFC_HIP(hipMemcpy(pyrow.p, rowky.data(), rowky.size() * sizeof(int), hipMemcpyHostToDevice));
+
+    // z-even symbol: store only kz <= Lz/2 per line; the kernel fetches the mirror values of its upper slots from
+    // the threads that loaded them (through LDS).  Needs: storage slots s < Lz/2 <-> kz < Lz/2 (true for every
+    // factorisation in fft_configs.hpp, re-checked here).
+    bool zeven = false;
+    const char* envz = getenv("LSFC_SYM_EVEN_Z");
+    if (!(envz && envz[0] == '0') && p->ndim == 3 && Lz >= 32) {
+        bool ok = true;
+        for (int s2 = 0; s2 < Lz; ++s2) if ((perm_z[s2] < Lz / 2) != (s2 < Lz / 2)) ok = false;
+        if (ok) zeven = pw_mirror_deviation(G2, p->pads, 2, p->stream) < 1e-13;
+    }
+    if (zeven) {
+        std::vector<int> invz((size_t)Lz), zm((size_t)Lz / 2);
+        for (int s2 = 0; s2 < Lz; ++s2) invz[perm_z[s2]] = s2;
+        for (int s2 = Lz / 2; s2 < Lz; ++s2) {
+            const int km = (Lz - perm_z[s2]) % Lz;                  // in [1, Lz/2]
+            zm[s2 - Lz / 2] = (km == Lz / 2) ? Lz / 2 : invz[km];
+        }
+        p->sym_hz = Lz / 2 + 8;
+        p->zmirror.alloc(zm.size());
+        LSFC_HIP(hipMemcpy(p->zmirror.p, zm.data(), zm.size() * sizeof(int), hipMemcpyHostToDevice));
+    } else {
+        p->sym_hz = Lz;
+        p->zmirror.release();
+    }
 }
 
 void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
@@ -180,12 +205,12 @@ void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
         }
         if (p->ndim == 3) {
             DevBuf<int> pyrow;
-            plan_setup_symbol_rows(p, G2.p, perm[1], pyrow);
-            p->sym.alloc((size_t)p->pads[0] * p->sym_rows * p->pads[2]);
-            pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, 0, p->pads[0] / 8, scale, p->stream);
+            plan_setup_symbol_rows(p, G2.p, perm[1], perm[2], pyrow);
+            p->sym.alloc((size_t)p->pads[0] * p->sym_rows * p->sym_hz);
+            pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, p->sym_hz, 0, p->pads[0] / 8, scale, p->stream);
         } else {
             p->sym.alloc((size_t)total);
-            pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, p->pads[1], 0, p->pads[0] / 8, scale, p->stream);
+            pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, p->pads[1], 1, 0, p->pads[0] / 8, scale, p->stream);
         }
         LSFC_HIP(hipStreamSynchronize(p->stream));
         G2.release();
@@ -253,10 +278,11 @@ void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
             const int p1 = p->pitch1, p2 = p->pitch2;
             pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, p1, p2, st);
             pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
-                          (int64_t)p2 * Ly, (int64_t)p2, 8, (int64_t)8 * Lz * p->sym_rows, (int64_t)8 * Lz, 8, p->ytab.p, st);
+                          (int64_t)p2 * Ly, (int64_t)p2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p,
+                          p->zmirror.p, st);
             pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p1, p2, st);
         } else {
-            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, st);
+            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, st);
         }
         pruned_xinv(Lx, p->tuning, p->A1.p, x, y, alpha, beta, p->tw[0].p, nlines, Lx, p->pitch1, st);
     } else {
@@ -577,10 +603,11 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
             if (p->ndim == 3) {
                 stages.push_back({"yfwd", (2 + 4) * N * C, [=] { pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, p->pitch1, p->pitch2, st); }});
                 stages.push_back({"zfused", (4 + 8 + 4) * N * C, [=] { pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
-                                  (int64_t)p->pitch2 * Ly, (int64_t)p->pitch2, 8, (int64_t)8 * Lz * p->sym_rows, (int64_t)8 * Lz, 8, p->ytab.p, st); }});
+                                  (int64_t)p->pitch2 * Ly, (int64_t)p->pitch2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8,
+                                  p->ytab.p, p->zmirror.p, st); }});
                 stages.push_back({"yinv", (4 + 2) * N * C, [=] { pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p->pitch1, p->pitch2, st); }});
             } else {
-                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, st); }});
+                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, st); }});
             }
             stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, Lx, p->pitch1, st); }});
         } else {

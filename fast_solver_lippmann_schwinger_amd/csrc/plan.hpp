@@ -85,6 +85,9 @@ struct lsfc_plan {
     // y-even symbol: only rows with ky <= Ly/2 are stored (sym_rows of them); ytab[o] = (data row, symbol row) in block order
     int sym_rows = 0;
     lsfc::DevBuf<int2> ytab;
+    // z-even symbol: lines hold sym_hz = Lz/2 + 8 entries (kz <= Lz/2); zmirror[s - Lz/2] = storage index of the mirror of slot s
+    int sym_hz = 0;
+    lsfc::DevBuf<int> zmirror;
     int pitch1 = 0, pitch2 = 0;      // row pitch of A1 (>= Lx) and of one storage-y row of an A2 tile (>= 8*l)
 
     // rocFFT pipelines
@@ -136,7 +139,7 @@ void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y,
 
 // symbol rows / block order of the z pass for a (possibly) y-even symbol: fills p->sym_rows, p->ytab, returns the
 // device table of the y frequency of every stored row (plan.hip)
-void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>& perm_y, DevBuf<int>& pyrow);
+void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>& perm_y, const std::vector<int>& perm_z, DevBuf<int>& pyrow);
 
 // GMRES (gmres.hip)
 void gmres_run(lsfc_plan* p, cplx* x_dev, const cplx* b_dev, const lsfc_gmres_opts* opts, double* resnorm, int64_t cap,

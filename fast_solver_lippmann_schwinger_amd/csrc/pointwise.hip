@@ -102,31 +102,39 @@ __global__ void k_wrap_crop(const cplx* __restrict__ src, cplx* __restrict__ dst
 // pruned pipeline.  3D: out[xi + 8*(sz + Lz*(sy + Ly*xb))];  2D (Lz==1): out[sx + Lx*sy].
 // 3D: `rows` symbol rows per tile; pyrow[r] = y frequency of row r (rows == Ly: every storage row; rows == Ly/2+1:
 // only the rows with ky <= Ly/2 of a y-even symbol, shared by the mirror rows).
+// hz: entries per symbol line.  hz == Lz: all storage slots.  hz == Lz/2 + 8 (z-even symbol): slots j < Lz/2 in
+// storage order (frequencies kz < Lz/2), slot Lz/2 = the kz = Lz/2 entry, the rest padding.
 __global__ void k_permute_symbol(const cplx* __restrict__ G2, cplx* __restrict__ out, const int* __restrict__ px,
-                                 const int* __restrict__ pyrow, const int* __restrict__ pz, int Lx, int Ly, int Lz, int rows,
+                                 const int* __restrict__ pyrow, const int* __restrict__ pz, int Lx, int Ly, int Lz, int rows, int hz,
                                  int xb0, int ntiles, double scale) {
-    const int64_t total = (Lz > 1) ? (int64_t)8 * Lz * rows * ntiles : (int64_t)Lx * Ly;
+    const int64_t total = (Lz > 1) ? (int64_t)8 * hz * rows * ntiles : (int64_t)Lx * Ly;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        int sx, sy, sz;
+        int sx, sy, kz = 0;
+        bool pad = false;
         if (Lz > 1) {
             const int xi = (int)(idx % 8); int64_t r = idx / 8;
-            sz = (int)(r % Lz); r /= Lz; sy = (int)(r % rows); const int xb = (int)(r / rows);
+            const int j = (int)(r % hz); r /= hz; sy = (int)(r % rows); const int xb = (int)(r / rows);
             sx = (xb0 + xb) * 8 + xi;
-        } else { sx = (int)(idx % Lx); sy = (int)(idx / Lx); sz = 0; }
-        const int kx = px[sx], ky = pyrow[sy], kz = (Lz > 1) ? pz[sz] : 0;
-        const cplx v = G2[kx + (int64_t)Lx * (ky + (int64_t)Ly * kz)];
+            if (hz == Lz) kz = pz[j];
+            else if (j < Lz / 2) kz = pz[j];
+            else if (j == Lz / 2) kz = Lz / 2;
+            else pad = true;
+        } else { sx = (int)(idx % Lx); sy = (int)(idx / Lx); }
+        cplx v = make_double2(0.0, 0.0);
+        if (!pad) v = G2[px[sx] + (int64_t)Lx * (pyrow[sy] + (int64_t)Ly * kz)];
         out[idx] = make_double2(scale * v.x, scale * v.y);
     }
 }
 
-// partial[2b] = max |G[..ky..] - G[..(Ly-ky)..]|, partial[2b+1] = max |G| over the slice of block b
-__global__ void k_ymirror_dev(const cplx* __restrict__ G, double* __restrict__ partial, int Lx, int Ly, int Lz) {
+// partial[2b] = max |G[..k..] - G[..(L-k)..]| along `axis`, partial[2b+1] = max |G| over the slice of block b
+__global__ void k_mirror_dev(const cplx* __restrict__ G, double* __restrict__ partial, int Lx, int Ly, int Lz, int axis) {
     __shared__ double sh[2][4];
     const int64_t total = (int64_t)Lx * Ly * Lz;
     double dmax = 0.0, amax = 0.0;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(idx % Lx); const int64_t r = idx / Lx; const int j = (int)(r % Ly); const int k = (int)(r / Ly);
-        const cplx a = G[idx], b = G[i + (int64_t)Lx * (((Ly - j) % Ly) + (int64_t)Ly * k)];
+        const int mj = axis == 1 ? (Ly - j) % Ly : j, mk = axis == 2 ? (Lz - k) % Lz : k, mi = axis == 0 ? (Lx - i) % Lx : i;
+        const cplx a = G[idx], b = G[mi + (int64_t)Lx * (mj + (int64_t)Ly * mk)];
         dmax = fmax(dmax, fmax(fabs(a.x - b.x), fabs(a.y - b.y)));
         amax = fmax(amax, fmax(fabs(a.x), fabs(a.y)));
     }
@@ -140,10 +148,10 @@ __global__ void k_ymirror_dev(const cplx* __restrict__ G, double* __restrict__ p
         partial[2 * blockIdx.x] = dmax; partial[2 * blockIdx.x + 1] = amax;
     }
 }
-double pw_ymirror_deviation(const cplx* G, const int L[3], hipStream_t st) {
+double pw_mirror_deviation(const cplx* G, const int L[3], int axis, hipStream_t st) {
     const int blocks = 1024;
     DevBuf<double> part; part.alloc(2 * blocks);
-    hipLaunchKernelGGL(k_ymirror_dev, dim3(blocks), dim3(256), 0, st, G, part.p, L[0], L[1], L[2]);
+    hipLaunchKernelGGL(k_mirror_dev, dim3(blocks), dim3(256), 0, st, G, part.p, L[0], L[1], L[2], axis);
     LSFC_HIP(hipGetLastError());
     std::vector<double> h(2 * blocks);
     LSFC_HIP(hipMemcpyAsync(h.data(), part.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -170,9 +178,9 @@ void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], do
     hipLaunchKernelGGL(k_wrap_crop, dim3(grid_for(total)), dim3(256), 0, st, src, dst, p[0], p[1], p[2], q[0], q[1], q[2], scale);
     LSFC_HIP(hipGetLastError());
 }
-void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int xb0, int ntiles, double scale, hipStream_t st) {
-    const int64_t total = (L[2] > 1) ? (int64_t)8 * L[2] * rows * ntiles : (int64_t)L[0] * L[1];
-    hipLaunchKernelGGL(k_permute_symbol, dim3(grid_for(total)), dim3(256), 0, st, G2, out, px, pyrow, pz, L[0], L[1], L[2], rows, xb0, ntiles, scale);
+void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int hz, int xb0, int ntiles, double scale, hipStream_t st) {
+    const int64_t total = (L[2] > 1) ? (int64_t)8 * hz * rows * ntiles : (int64_t)L[0] * L[1];
+    hipLaunchKernelGGL(k_permute_symbol, dim3(grid_for(total)), dim3(256), 0, st, G2, out, px, pyrow, pz, L[0], L[1], L[2], rows, hz, xb0, ntiles, scale);
     LSFC_HIP(hipGetLastError());
 }
 void pw_scale(cplx* a, double s, int64_t total, hipStream_t st) {
@@ -270,21 +278,33 @@ __global__ __launch_bounds__(64) void k_finish(const cplx* __restrict__ partial,
     if (threadIdx.x == 0) { if (mode == 1) acc = make_double2(sqrt(acc.x), 0.0); *out = acc; }
 }
 
-// multi-dot for classical Gram-Schmidt: partial[j*RED_BLOCKS + b] = sum conj(V_j) * w, j < k (k <= 32 per launch)
+// multi-dot for classical Gram-Schmidt: partial[j*RED_BLOCKS + b] = sum conj(V_j) * w for NC columns at once, so w is
+// read once per group of NC columns instead of once per column
+template <int NC>
 __global__ __launch_bounds__(RED_THREADS) void k_multidot_partial(const cplx* __restrict__ V, int64_t ldv, int k, const cplx* __restrict__ w,
                                                                    cplx* __restrict__ partial, int64_t n) {
     __shared__ cplx sh[RED_THREADS / 64];
-    for (int j = 0; j < k; ++j) {
-        const cplx* a = V + (int64_t)j * ldv;
-        cplx acc = make_double2(0.0, 0.0);
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-            const cplx u = a[i], v = w[i];
-            acc.x = fma(u.x, v.x, fma(u.y, v.y, acc.x));
-            acc.y = fma(u.x, v.y, fma(-u.y, v.x, acc.y));
+    cplx acc[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) acc[j] = make_double2(0.0, 0.0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cplx v = w[i];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            if (j < k) {
+                const cplx u = V[(int64_t)j * ldv + i];
+                acc[j].x = fma(u.x, v.x, fma(u.y, v.y, acc[j].x));
+                acc[j].y = fma(u.x, v.y, fma(-u.y, v.x, acc[j].y));
+            }
         }
-        const cplx r = block_sum(acc, sh);
-        if (threadIdx.x == 0) partial[(int64_t)j * RED_BLOCKS + blockIdx.x] = r;
-        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        if (j < k) {
+            const cplx r = block_sum(acc[j], sh);
+            if (threadIdx.x == 0) partial[(int64_t)j * RED_BLOCKS + blockIdx.x] = r;
+            __syncthreads();
+        }
     }
 }
 __global__ __launch_bounds__(64) void k_multifinish(const cplx* __restrict__ partial, int count, cplx* __restrict__ out) {
@@ -346,7 +366,12 @@ void blas_axpy_dot(cplx* w, const cplx* v, const cplx* h, const cplx* vnext, cpl
     LSFC_HIP(hipGetLastError());
 }
 void blas_multidot(const cplx* V, int64_t ldv, int k, const cplx* w, cplx* partial, cplx* out, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(k_multidot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, V, ldv, k, w, partial, n);
+    constexpr int NC = 8;
+    for (int j0 = 0; j0 < k; j0 += NC) {
+        const int kc = k - j0 < NC ? k - j0 : NC;
+        hipLaunchKernelGGL(k_multidot_partial<NC>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, V + (int64_t)j0 * ldv, ldv, kc, w,
+                           partial + (int64_t)j0 * RED_BLOCKS, n);
+    }
     hipLaunchKernelGGL(k_multifinish, dim3(k), dim3(64), 0, st, partial, RED_BLOCKS, out);
     LSFC_HIP(hipGetLastError());
 }

@@ -13,9 +13,9 @@ void pw_crop_axpy(const cplx* W, const cplx* x, cplx* y, double alpha, double be
 void pw_roll_scale(const cplx* src, cplx* dst, const int p[3], const int s[3], double scale, hipStream_t);
 void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], double scale, hipStream_t);
 // 3D: tiles [xb0, xb0+ntiles) of the x' axis only (the symbol slab of one rank); 2D: whole symbol
-void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int xb0, int ntiles, double scale, hipStream_t);
-// max |G(ky) - G(Ly-ky)| / max |G| of a natural-order symbol (1.0 if it contains NaN)
-double pw_ymirror_deviation(const cplx* G, const int L[3], hipStream_t);
+void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int hz, int xb0, int ntiles, double scale, hipStream_t);
+// max |G(k) - G(L-k)| / max |G| along `axis` of a natural-order symbol (1.0 if it contains NaN)
+double pw_mirror_deviation(const cplx* G, const int L[3], int axis, hipStream_t);
 void pw_scale(cplx* a, double s, int64_t total, hipStream_t);
 
 void pw_gather_sources(const cplx* K, cplx* out, const int64_t* src, int nsrc, const int dims[3], hipStream_t);

@@ -32,6 +32,7 @@ void pruned_yfwd(int L, const PrunedTuning&, const cplx* a1, cplx* a2, const cpl
 void pruned_yinv(int L, const PrunedTuning&, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);
 void pruned_zfused(int L, const PrunedTuning&, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                   const int2* ytab /* block order -> (data row, symbol row); NULL: identity */, hipStream_t);
+                   const int2* ytab /* block order -> (data row, symbol row); NULL: identity */,
+                   const int* zm /* z-even symbol: partner storage index of every upper-half slot; NULL: full symbol lines */, hipStream_t);
 
 } // namespace lsfc
