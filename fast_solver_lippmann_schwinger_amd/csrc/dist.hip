@@ -205,7 +205,7 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     std::vector<int> perm[3]; DevBuf<int> dperm[3];
     for (int a = 0; a < 3; ++a) {
         perm[a].resize((size_t)p->pads[a]);
-        pruned_perm(p->pads[a], a == 1 ? p->tuning.cfg_y : (a == 2 ? p->tuning.cfg_z : 0), perm[a].data());
+        pruned_perm(p->pads[a], perm[a].data());
         dperm[a].alloc(perm[a].size());
         LSFC_HIP(hipMemcpy(dperm[a].p, perm[a].data(), perm[a].size() * sizeof(int), hipMemcpyHostToDevice));
         make_twiddles_dist(p.get(), a, p->pads[a]);

@@ -10,6 +10,7 @@ using Cfg256  = Cfg<256, 32,  8,  8, 4>;
 using Cfg512  = Cfg<512, 64,  8,  8, 8>;
 using Cfg1024 = Cfg<1024, 64, 16, 8, 8>;
 using Cfg2048 = Cfg<2048, 128, 16, 16, 8>;
-// 8 elements per thread: half the registers of Cfg1024 (4 waves/SIMD instead of 2) for one more LDS exchange
+// four-stage, 8 elements per thread: half the registers of Cfg1024 for one more LDS exchange.  Measured slower on
+// MI355X (profiles/r01_experiment_e8_four_stage.log); kept as the tested instance of the 4-stage machinery.
 using Cfg1024S = Cfg<1024, 128, 8, 8, 4, 4>;
 }} // namespace

@@ -147,8 +147,10 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
 // symbol entry for storage index s at sym[g*sGrp + outer*sOuter + xi + sLine*s].
 // PREFETCH: the symbol loads are issued before the forward transform, so their HBM latency hides behind its
 // butterflies (+E complex registers; pays at E = 16 where the kernel runs at 2 waves/SIMD either way).
-// Tried and dropped (profiles/r01_experiment_*.log): LDS-only exchange barriers, non-temporal accesses, and a
-// persistent software-pipelined form of all five kernels (register pressure and spills cost more than the overlap won).
+// Tried and dropped (profiles/r01_experiment_*.log): LDS-only exchange barriers, non-temporal accesses, a persistent
+// software-pipelined form of all five kernels, 128-register builds (two 512-thread workgroups per CU), an
+// 8-elements-per-thread four-stage factorisation of the 1024-point line, and Infinity-Cache slab blocking of the
+// y/z/y passes -- each measured slower or neutral on MI355X.
 // HALF: the workgroup transforms only 4 of the 8 interleaved lines of a tile (64 B of every 128-B line); the two
 // halves of a tile are blocks b and b+8 of a group of 16, i.e. (by the observed round-robin placement) on the SAME
 // XCD, whose L2 merges their reads and writes of the shared lines.  Halving the workgroup to 4 waves lets two (or
@@ -308,8 +310,6 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     }
 }
 
-static bool occ2_for(int knob, int L) { return L == 1024 && knob > 0; }
-
 // half-tile z pass (L = 1024 in 3D tiled layout only): 4-line workgroups, sibling halves 8 blocks apart
 template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static void zfused_half_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                                                          int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
@@ -342,16 +342,12 @@ static bool env_flag(const char* name, bool dflt) {
     case 2048: { using C = Cfg2048; CALL; } break;                         \
     default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); }
 
-// strided passes: at L = 1024 the 8-elements-per-thread factorisation can replace the 16-element one
-#define LSFC_DISPATCH_LV(L, V, CALL)                                       \
-    if ((L) == 1024 && (V) == 1) { using C = Cfg1024S; CALL; } else { LSFC_DISPATCH_L(L, CALL) }
-
 bool pruned_length_supported(int64_t L) {
     return L == 32 || L == 64 || L == 128 || L == 256 || L == 512 || L == 1024 || L == 2048;
 }
 
-void pruned_perm(int L, int variant, int* freq_of_storage) {
-    LSFC_DISPATCH_LV(L, variant, perm_table<C>(freq_of_storage));
+void pruned_perm(int L, int* freq_of_storage) {
+    LSFC_DISPATCH_L(L, perm_table<C>(freq_of_storage));
 }
 
 PrunedTuning pruned_default_tuning() {
@@ -362,10 +358,6 @@ PrunedTuning pruned_default_tuning() {
     if (const char* v = getenv("LSFC_PAD1")) t.pad1 = atoi(v);
     if (const char* v = getenv("LSFC_PAD2")) t.pad2 = atoi(v);
     if (const char* v = getenv("LSFC_Z_HALF")) t.z_half = atoi(v);
-    if (const char* v = getenv("LSFC_CFG_Y")) t.cfg_y = atoi(v);
-    if (const char* v = getenv("LSFC_CFG_Z")) t.cfg_z = atoi(v);
-    if (const char* v = getenv("LSFC_OCC2_Y")) t.occ2_y = atoi(v);
-    if (const char* v = getenv("LSFC_OCC2_Z")) t.occ2_z = atoi(v);
     if (const char* v = getenv("LSFC_SYM_PREFETCH")) t.sym_prefetch = atoi(v);
     if (const char* v = getenv("LSFC_YTILE_G")) t.ytile_g = atoi(v);
     if (const char* v = getenv("LSFC_YTILE_Z")) t.ytile_z = atoi(v);
@@ -387,28 +379,24 @@ void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, 
     LSFC_HIP(hipGetLastError());
 }
 void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
-    // occ2: cap registers at 128 so that two 512-thread workgroups share a CU (needs the split LDS layout)
-    if (occ2_for(tn.occ2_y, L) && !tn.cfg_y) { using C = Cfg1024; yfwd_t<C, true, 4>(tn, a1, a2, tw, Lx, m, l, p1, p2, st); }
-    else if (tn.split_s) { LSFC_DISPATCH_LV(L, tn.cfg_y, (yfwd_t<C, true, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
-    else                 { LSFC_DISPATCH_LV(L, tn.cfg_y, (yfwd_t<C, false, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
+    if (tn.split_s) { LSFC_DISPATCH_L(L, (yfwd_t<C, true, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
+    else            { LSFC_DISPATCH_L(L, (yfwd_t<C, false, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
     LSFC_HIP(hipGetLastError());
 }
 void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
-    if (occ2_for(tn.occ2_y, L) && !tn.cfg_y) { using C = Cfg1024; yinv_t<C, true, 4>(tn, a2, a1, tw, Lx, m, l, p1, p2, st); }
-    else if (tn.split_s) { LSFC_DISPATCH_LV(L, tn.cfg_y, (yinv_t<C, true, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
-    else                 { LSFC_DISPATCH_LV(L, tn.cfg_y, (yinv_t<C, false, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
+    if (tn.split_s) { LSFC_DISPATCH_L(L, (yinv_t<C, true, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
+    else            { LSFC_DISPATCH_L(L, (yinv_t<C, false, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
     LSFC_HIP(hipGetLastError());
 }
 void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, const int2* ytab,
                    const int* zm, hipStream_t st) {
-#define LSFC_ZF(SP, PF) do { if (zm) { LSFC_DISPATCH_LV(L, zvariant, (zfused_t<C, SP, PF, 1, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st))); } \
-                             else    { LSFC_DISPATCH_LV(L, zvariant, (zfused_t<C, SP, PF, 1, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st))); } } while (0)
-    const int zvariant = (dLine == 8) ? tn.cfg_z : tn.cfg_y;      // 2D: the fused pass runs along y
+#define LSFC_ZF(SP, PF) do { if (zm) { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st))); } \
+                             else    { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st))); } } while (0)
     // auto (-1): half-tile, split exchanges, symbol prefetch -- 6.95 -> 6.6 ms at 512^3 (profiles/r01_experiment_half_tile.log)
     // with the z-even half symbol the full-tile form wins (6.05 ms, profiles/r01_experiment_even_z.log)
     const int zh = tn.z_half >= 0 ? tn.z_half : (zm ? 0 : 2);
-    if (L == 1024 && zh > 0 && !tn.cfg_z && dLine == 8 && ((int64_t)(Lx / XB) * nouter) % 8 == 0) {
+    if (L == 1024 && zh > 0 && dLine == 8 && ((int64_t)(Lx / XB) * nouter) % 8 == 0) {
         using C = Cfg1024;
 #define LSFC_ZH(SP, PF, W) do { if (zm) zfused_half_t<C, SP, PF, W, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st); \
                                 else zfused_half_t<C, SP, PF, W, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st); } while (0)
@@ -422,16 +410,9 @@ void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, c
         LSFC_HIP(hipGetLastError());
         return;
     }
-    if (occ2_for(tn.occ2_z, L) && !zvariant) {
-        using C = Cfg1024;
-        LSFC_REQUIRE(!zm, "occ2_z: not available with a z-even symbol");
-        zfused_t<C, true, false, 4>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st);
-        LSFC_HIP(hipGetLastError());
-        return;
-    }
     // auto (-1): measured on MI355X -- at L >= 1024 (16 elements/thread, 2 waves/SIMD either way) whole-complex
     // exchanges + symbol prefetch win (7.4 -> 6.7 ms at 512^3); below, split exchanges without prefetch (more waves)
-    const bool e16 = L >= 1024 && !zvariant;
+    const bool e16 = L >= 1024;
     const bool sp = tn.split_z >= 0 ? tn.split_z != 0 : !e16;
     const bool pf = tn.sym_prefetch >= 0 ? tn.sym_prefetch != 0 : e16;
     if (sp) { if (pf) { LSFC_ZF(true, true); } else { LSFC_ZF(true, false); } }

@@ -197,8 +197,7 @@ void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
         DevBuf<int> dperm[3];
         for (int d = 0; d < p->ndim; ++d) {
             perm[d].resize((size_t)p->pads[d]);
-            // x passes always use the default factorisation; the y / z storage orders follow the strided passes' variant
-            pruned_perm(p->pads[d], d == 1 ? p->tuning.cfg_y : (d == 2 ? p->tuning.cfg_z : 0), perm[d].data());
+            pruned_perm(p->pads[d], perm[d].data());
             dperm[d].alloc(perm[d].size());
             LSFC_HIP(hipMemcpy(dperm[d].p, perm[d].data(), perm[d].size() * sizeof(int), hipMemcpyHostToDevice));
             make_twiddles(p, d, p->pads[d]);
@@ -552,8 +551,6 @@ int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value) {
         else if (k == "split_s") plan->tuning.split_s = value != 0;
         else if (k == "split_z") plan->tuning.split_z = value;
         else if (k == "z_half") plan->tuning.z_half = value;
-        else if (k == "occ2_y") plan->tuning.occ2_y = value;
-        else if (k == "occ2_z") plan->tuning.occ2_z = value;
         else if (k == "sym_prefetch") plan->tuning.sym_prefetch = value;
         else if (k == "ytile_g") plan->tuning.ytile_g = value;
         else if (k == "ytile_z") plan->tuning.ytile_z = value;

@@ -10,9 +10,7 @@ struct PrunedTuning {
     int split_z = -1;      // fused z pass: 1 split, 0 whole complex, -1 auto (by line length)
     int sym_prefetch = -1; // z pass: load the symbol before the forward transform; -1 auto
     int pad1 = -1, pad2 = -1;        // row padding (elements, multiples of 8) of the A1 rows / A2 tile rows, read at plan creation
-    int cfg_y = 0, cfg_z = 0;       // factorisation variant of the y / z passes; fixed at plan creation (defines the storage order)
-    int z_half = -1;                // L = 1024 z pass: half-tile 4-wave workgroups (1: full+prefetch, 2: split+prefetch, 3: split, 3 WG/CU, 4: full)
-    int occ2_y = 0, occ2_z = 0;     // L = 1024 only: 128-register builds of the y / z passes (two workgroups per CU)
+    int z_half = -1;                // L = 1024 z pass: half-tile 4-wave workgroups (0 off, 1: full+prefetch, 2: split+prefetch, 3: split 3 WG/CU, 4: full; -1 auto)
     int ytile_g = 0, ytile_z = 0;   // y passes: block-order tile (x'-groups x z planes); 0 = auto
 };
 
@@ -20,8 +18,7 @@ bool pruned_length_supported(int64_t L);
 // W = chunk width of the x'-storage axis in the xfwd output / xinv input: out[s / W][line][s % W] (W = L on one GPU;
 // W = L / nranks packs the slab transpose for free).
 // freq_of_storage[s] = frequency index held at storage index s after the forward pass of length L
-// variant: factorisation used by the strided passes along that axis (0 default; 1 at L = 1024: 8 elements per thread)
-void pruned_perm(int L, int variant, int* freq_of_storage);
+void pruned_perm(int L, int* freq_of_storage);
 PrunedTuning pruned_default_tuning();
 
 void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, hipStream_t);

@@ -229,3 +229,49 @@ def test_device_resident_vectors_torch(lsfc):
     assert ms > 0
     prof = lsfc.profile_apply(M, xb, y, 2)
     assert [p[0] for p in prof] == ["xfwd", "yfwd", "zfused", "yinv", "xinv"]
+
+
+# ---------------------------------------------------------------------------- error behaviour and edge cases through the C ABI
+def test_error_paths_and_edge_cases(lsfc):
+    import ctypes as C
+    from fast_solver_lippmann_schwinger_amd import _lib as L
+    lib = lsfc.load()
+    c = cases.case_3d("gv16")
+    Mo, b, n = c["M"], c["b"], c["n"]
+    M = lsfc.FastM3D(Mo.GFFT, Mo.nu, Mo.ne, Mo.me, Mo.le, n, n, n, Mo.omega)
+    # DimensionMismatch on the vector length (the reference throws from reshape / broadcasting)
+    with pytest.raises(ValueError):
+        M * b[:-1]
+    with pytest.raises(ValueError):
+        lsfc.FastM3D(Mo.GFFT, Mo.nu[:-1], Mo.ne, Mo.me, Mo.le, n, n, n, Mo.omega)
+    # C ABI: NULL arguments, bad quadRule, too-small padded grid, odd n in the 3D builder, even n in the trapezoidal builder
+    plan = C.c_void_p()
+    nu = np.zeros(n ** 3)
+    assert lib.lsfc_apply(None, None, None, 0) == -1 and b"NULL" in lib.lsfc_last_error()
+    G = np.asfortranarray(Mo.GFFT)
+    assert lib.lsfc_plan_create_3d(C.byref(plan), n, n, n, 4 * n, 4 * n, 4 * n, nu.ctypes.data_as(C.c_void_p), G.ctypes.data_as(C.c_void_p), 1.0, 7, 0, 0) == -1
+    assert b"quadRule" in lib.lsfc_last_error()
+    assert lib.lsfc_plan_create_3d(C.byref(plan), n, n, n, n, n, n, nu.ctypes.data_as(C.c_void_p), G.ctypes.data_as(C.c_void_p), 1.0, 1, 0, 0) == -1
+    assert lib.lsfc_plan_create_gv3d(C.byref(plan), 15, 16, 16, 1.0, 5.0, nu.ctypes.data_as(C.c_void_p), 0, 0) == -1
+    assert lib.lsfc_plan_create_trap2d(C.byref(plan), 20, 21, -0.5, -0.5, 0.05, 20.0, 1.0, -0.892, nu.ctypes.data_as(C.c_void_p), 0, 0) == -1
+    assert b"n odd" in lib.lsfc_last_error()
+    assert lib.lsfc_plan_create_gv3d(C.byref(plan), 16, 16, 16, 1.0, 5.0, nu.ctypes.data_as(C.c_void_p), 0, 99) == -1     # no such device
+    assert lib.lsfc_plan_destroy(None) == 0
+    # unknown tuning key; sample index out of range
+    assert lib.lsfc_plan_set_tuning(M._plan, b"nonsense", 1) == -1
+    src = np.array([n ** 3], dtype=np.int64); out = np.empty(n ** 3, complex)
+    assert lib.lsfc_sample_sources(M._plan, src.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p), 0) == -1
+    # batch entry == repeated single applies; zero vector maps to zero; smallest supported pruned grid is n = 16
+    X = np.stack([b, 2j * b, np.zeros_like(b)])
+    Y = np.empty_like(X)
+    L.check(lib.lsfc_apply_batch(M._plan, X.ctypes.data_as(C.c_void_p), Y.ctypes.data_as(C.c_void_p), 3, 0, 0))
+    y = M * b
+    assert np.array_equal(Y[0], y) and rel_err(Y[1], 2j * y) < 1e-15 and not Y[2].any()
+    # n = 8 (padded length 16) is below the hand-written range: the rocFFT pipeline takes over, same results
+    n8 = 8
+    rng = np.random.default_rng(2)
+    G8 = rng.standard_normal((4 * n8,) * 3) + 1j * rng.standard_normal((4 * n8,) * 3)
+    nu8 = rng.uniform(-0.3, 0.3, n8 ** 3); b8 = o.random_vector(n8 ** 3)
+    M8 = lsfc.FastM3D(G8, nu8, 4 * n8, 4 * n8, 4 * n8, n8, n8, n8, 2.0)
+    assert M8.pipeline == "rocfft-reduced"
+    assert rel_err(M8 * b8, o.apply_reduced(o.reduce_symbol(G8, (n8,) * 3), nu8, 2.0, b8, (n8,) * 3)) < TOL
