@@ -91,7 +91,9 @@ void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
     LSFC_REQUIRE(!d->sim, "simulated ranks are driven through lsfc_dist_sim_apply");
     hipStream_t st = p->stream;
     phase1(p, x, use_nu, st);
-    if (d->nranks == 1 && !d->force_overlap) {
+    // LSFC_DIST_OVERLAP=0: no overlap -- every exchange on the compute stream, chunk after chunk (debugging aid)
+    static const bool no_overlap = getenv("LSFC_DIST_OVERLAP") && getenv("LSFC_DIST_OVERLAP")[0] == '0';
+    if ((d->nranks == 1 && !d->force_overlap) || no_overlap) {
         for (int c = 0; c < d->K; ++c) { exchange(p, c, false, st); phase2(p, c, st); exchange(p, c, true, st); }
         phase3(p, x, y, alpha, beta, st);
         return;

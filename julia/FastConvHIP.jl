@@ -96,6 +96,16 @@ function FFTconvolution(M::FastMHIP, b::Array{Complex{Float64},1})
     y
 end
 
+# sampleG3D(k,X,Y,Z,indS,fastconv) / sampleGConv -- src/FastConvolution3D.jl:136-160, src/FastConvolution.jl:278-306
+# (1-based indS as in the reference; rows of the result are the responses to the delta sources)
+function sampleG3D(k, X, Y, Z, indS, M::FastMHIP)
+    N = length(M.nu); ns = length(indS)
+    out = Array{Complex{Float64}}(undef, N, ns); src = Int64.(indS .- 1)
+    check(ccall((:lsfc_sample_sources, liblsfc), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64, Ptr{Complex{Float64}}, Cint), M.plan, src, ns, out, 0))
+    return permutedims(out)          # (ns, N) like the reference's Gc
+end
+sampleGConv(k, X, Y, indS, M::FastMHIP) = sampleG3D(k, X, Y, nothing, indS, M)
+
 # Device-side GMRES with a host preconditioner: Pl is anything with the two-argument ldiv!(Pl, v)
 # (src/preconditioner.jl:147-170), passed through @cfunction.
 struct GmresOpts
