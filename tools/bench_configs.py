@@ -77,11 +77,29 @@ def bench_hf(n=512):
     return {"config": f"3D n={n} omega=64pi patched symbol", "ms_per_apply": ms, "finite": bool(torch.isfinite(torch.view_as_real(yb)).all())}
 
 
+def bench_host_vectors(n=512):
+    """PCIe-inclusive rate: the same apply with HOST-resident x and y (LSFC_MEM_HOST), as the Julia wrapper's `*` does."""
+    h = 1.0 / n
+    x = -0.5 + h * np.arange(n)
+    nu = np.random.default_rng(0).uniform(-0.3, 0.3, n ** 3)
+    M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, 1.0 / h, nu)
+    b = np.random.default_rng(1).standard_normal(n ** 3) + 0j
+    y = np.empty_like(b)
+    M.mul_(y, b)
+    t0 = time.time()
+    for _ in range(3):
+        M.mul_(y, b)
+    t = (time.time() - t0) / 3
+    return {"config": f"3D n={n} apply with host vectors (PCIe inclusive, pageable numpy memory)", "ms_per_apply": 1e3 * t, "applies_per_s": 1 / t}
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["2d", "gmres", "hf"]
     res = []
     if "2d" in what: res.append(bench_2d())
     if "gmres" in what: res.append(bench_gmres())
     if "hf" in what: res.append(bench_hf())
+    if "gmres512" in what: res.append(bench_gmres(512))
+    if "host" in what: res.append(bench_host_vectors())
     for r in res:
         print(json.dumps(r), flush=True)
