@@ -31,12 +31,15 @@ def _is_torch(a):
     return type(a).__module__.split(".")[0] == "torch"
 
 
-def _vec(a, N, name, count=1):
-    """-> (pointer, memspace, keepalive)."""
+def _vec(a, N, name, count=1, plan=None):
+    """-> (pointer, memspace, keepalive).  For CUDA tensors the plan is moved onto torch's current stream, so the
+    library's kernels are ordered with the caller's torch work (stream 0 == the legacy default stream)."""
     if _is_torch(a):
         import torch
         if a.dtype != torch.complex128 or not a.is_contiguous() or a.numel() != N * count:
             raise TypeError(f"{name}: need a contiguous complex128 tensor with {N * count} entries")
+        if a.is_cuda and plan is not None:
+            L.check(L.load().lsfc_plan_set_stream(plan, C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
         return C.c_void_p(a.data_ptr()), (L.LSFC_MEM_DEVICE if a.is_cuda else L.LSFC_MEM_HOST), a
     arr = np.ascontiguousarray(a, dtype=np.complex128)
     if arr.size != N * count:
@@ -95,7 +98,7 @@ class _Operator:
 
     def mul_(self, Y, b):
         """LinearAlgebra.mul!(Y, M, b): Y[:] = M*b  (src/FastConvolution.jl:50-54)."""
-        px, sx, kx = _vec(b, self.N, "b")
+        px, sx, kx = _vec(b, self.N, "b", plan=self._plan)
         if _is_torch(Y):
             py, sy, _ = _vec(Y, self.N, "Y")
             if sy != sx:
@@ -210,7 +213,7 @@ def eltype(M):
 
 def fastconvolution(M, b):
     """b + omega^2 * G*(nu .* b)  (src/FastConvolution.jl:58-107; `*` of FastM3D)."""
-    px, sx, keep = _vec(b, M.N, "b")
+    px, sx, keep = _vec(b, M.N, "b", plan=M._plan)
     y = M._out_like(keep)
     py, _, _ = _vec(y, M.N, "y")
     L.check(L.load().lsfc_apply(M._plan, px, py, sx))
@@ -229,7 +232,7 @@ def FFTconvolution(M, b):
         # the reference allocates (ne, ne) and crops n in both dimensions (:120,:132): square grids only
         raise ValueError("DimensionMismatch: FFTconvolution(::FastM) assumes n == m")
     apply_nu = 1 if (isinstance(M, FastM) and M.quadRule == "trapezoidal") else 0
-    px, sx, keep = _vec(b, M.N, "b")
+    px, sx, keep = _vec(b, M.N, "b", plan=M._plan)
     y = M._out_like(keep)
     py, _, _ = _vec(y, M.N, "y")
     L.check(L.load().lsfc_convolve(M._plan, px, py, apply_nu, sx))
@@ -335,7 +338,7 @@ def gmres_(x, A, b, Pl=None, abstol=0.0, reltol=None, restart=None, maxiter=None
     ``Pl`` is a callable ``v -> None`` that overwrites the host numpy vector v with Pl \\ v -- the
     two-argument in-place ``ldiv!(Pl, v)`` of src/preconditioner.jl:147-170.  x is updated in place."""
     N = A.N
-    px, sx, keepx = _vec(x, N, "x")
+    px, sx, keepx = _vec(x, N, "x", plan=A._plan)
     pb, sb, keepb = _vec(b, N, "b")
     if sx != sb:
         raise TypeError("x and b must live in the same memory space")
