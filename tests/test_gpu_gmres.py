@@ -105,3 +105,15 @@ def test_gmres_2d_example_path(lsfc):
     u, hist = lsfc.gmres_(u, M, rhs, log=True)
     assert hist.isconverged
     assert np.linalg.norm(o.fastconvolution(c["M"], u) - rhs) / np.linalg.norm(rhs) < 1e-7
+
+
+def test_example_drivers_run(lsfc):
+    # the reference's two driver scripts, re-stated over the mirror (examples/), at reduced size
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, arg in [("example3D", 16), ("example", 1.0 / 32)]:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "examples", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        U, info = mod.main(arg)
+        assert info.isconverged and np.isfinite(U).all()
