@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=int(os.environ.get("LSFC_BENCH_N", 512)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (rehearsal of the multi-GPU path)")
     args = ap.parse_args()
 
     import torch
@@ -101,11 +102,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    if world == 1:
+    if world == 1 and not args.force_dist:
         nu = synthetic_nu(n, 0, n)
         x = -0.5 + h * np.arange(n)
         M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, omega, nu, device=local_rank)
@@ -151,7 +152,7 @@ def main():
     dom = max((s for s in stages if not s[0].startswith("alltoall")), key=lambda s: s[1])
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1:
         try:
             traffic = json.load(open(tpath)).get(dom[0])
         except Exception:

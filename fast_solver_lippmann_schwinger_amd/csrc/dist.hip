@@ -73,9 +73,17 @@ static void exchange(lsfc_plan* p, int c, bool back, hipStream_t st) {
     auto r1 = [&](int r) { return d->R1.p + ((int64_t)c * P + r) * B; };
     const cplx* self_src = back ? r1(d->rank) : s1(d->rank);
     cplx* self_dst = back ? s1(d->rank) : r1(d->rank);
+    ncclComm_t comm = (ncclComm_t)(back ? d->comm2 : d->comm);
+    if (d->force_comm && P == 1) {
+        // single-rank exercise of the RCCL path: the self block travels through ncclSend/ncclRecv
+        LSFC_NCCL(ncclGroupStart());
+        LSFC_NCCL(ncclSend(self_src, (size_t)B * 2, ncclDouble, 0, comm, st));
+        LSFC_NCCL(ncclRecv(self_dst, (size_t)B * 2, ncclDouble, 0, comm, st));
+        LSFC_NCCL(ncclGroupEnd());
+        return;
+    }
     LSFC_HIP(hipMemcpyAsync(self_dst, self_src, (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice, st));
     if (P == 1) return;
-    ncclComm_t comm = (ncclComm_t)(back ? d->comm2 : d->comm);
     LSFC_NCCL(ncclGroupStart());
     for (int s = 1; s < P; ++s) {
         // pairwise schedule: in step s every GPU talks to a different peer, so all xGMI links carry traffic at once
@@ -122,7 +130,7 @@ void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
 
 void dist_allreduce_sum(lsfc_plan* p, cplx* dev, int count) {
     DistState* d = p->dist.get();
-    if (!d || d->sim || d->nranks == 1) return;
+    if (!d || d->sim || (d->nranks == 1 && !d->force_comm)) return;
     LSFC_NCCL(ncclAllReduce(dev, dev, (size_t)count * 2, ncclDouble, ncclSum, (ncclComm_t)d->comm, p->stream));
 }
 
@@ -179,7 +187,9 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     d->K = K; d->Wc = d->W / K;
     // LSFC_DIST_FORCE_OVERLAP=1: run the three-stream pipeline even with one rank (tests of the event logic)
     d->force_overlap = getenv("LSFC_DIST_FORCE_OVERLAP") && getenv("LSFC_DIST_FORCE_OVERLAP")[0] == '1';
-    if (!sim && nranks > 1) {
+    // LSFC_DIST_FORCE_COMM=1: build the communicators and route the (self) exchange through RCCL even with one rank
+    d->force_comm = !sim && getenv("LSFC_DIST_FORCE_COMM") && getenv("LSFC_DIST_FORCE_COMM")[0] == '1';
+    if (!sim && (nranks > 1 || d->force_comm)) {
         LSFC_REQUIRE(id, "NULL unique id");
         ncclUniqueId uid; static_assert(sizeof(uid) == LSFC_UNIQUE_ID_BYTES, "unique id size");
         memcpy(&uid, id, sizeof uid);

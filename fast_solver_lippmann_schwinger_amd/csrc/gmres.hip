@@ -86,7 +86,7 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
     hipStream_t st = p->stream;
     auto Vcol = [&](int j) { return w->V.p + (size_t)j * (size_t)N; };
     // slab-distributed plan: every inner product / squared norm is completed by an all-reduce over the ranks
-    const bool multi = p->dist && !p->dist->sim && p->dist->nranks > 1;
+    const bool multi = p->dist && !p->dist->sim && (p->dist->nranks > 1 || p->dist->force_comm);
     auto finish_dot = [&](cplx* s, int count) { if (multi) dist_allreduce_sum(p, s, count); };
     auto finish_nrm = [&](cplx* s) { if (multi) { dist_allreduce_sum(p, s, 1); blas_sqrt_dev(s, st); } };
 

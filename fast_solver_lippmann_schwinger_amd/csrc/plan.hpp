@@ -44,7 +44,7 @@ struct GmresWorkspace {
 // slab-distributed state (dist.hip)
 struct DistState {
     int rank = 0, nranks = 1;
-    bool force_overlap = false;
+    bool force_overlap = false, force_comm = false;
     bool sim = false;        // simulated ranks in one process (tests): exchanges done by lsfc_dist_sim_apply
     void* comm = nullptr;    // ncclComm_t
     void* comm2 = nullptr;   // second communicator: the way back runs on its own stream, concurrently with the way in

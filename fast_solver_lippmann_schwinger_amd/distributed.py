@@ -29,7 +29,7 @@ def exchange_unique_id(rank, nranks, group=None):
     buf = (C.c_ubyte * L.LSFC_UNIQUE_ID_BYTES)()
     if rank == 0:
         L.check(L.load().lsfc_dist_unique_id(buf))
-    if nranks > 1:
+    if dist.is_available() and dist.is_initialized():
         backend = dist.get_backend(group)
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
