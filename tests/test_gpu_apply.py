@@ -275,3 +275,17 @@ def test_error_paths_and_edge_cases(lsfc):
     M8 = lsfc.FastM3D(G8, nu8, 4 * n8, 4 * n8, 4 * n8, n8, n8, n8, 2.0)
     assert M8.pipeline == "rocfft-reduced"
     assert rel_err(M8 * b8, o.apply_reduced(o.reduce_symbol(G8, (n8,) * 3), nu8, 2.0, b8, (n8,) * 3)) < TOL
+
+
+def test_c_api_example_compiles_and_runs(lsfc, tmp_path):
+    # the boundary is usable from plain C: examples/c_api_example.c built with gcc against liblsfc.so
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "fast_solver_lippmann_schwinger_amd")
+    exe = str(tmp_path / "c_api_example")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_api_example.c"),
+                        "-L", libdir, "-llsfc", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    r = subprocess.run([exe, "32"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+    assert b"converged=1" in r.stdout
