@@ -21,7 +21,8 @@ PRECOND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
 
 class GmresOpts(C.Structure):
     _fields_ = [("restart", C.c_int), ("maxiter", C.c_int64), ("reltol", C.c_double), ("abstol", C.c_double),
-                ("orth", C.c_int), ("initially_zero", C.c_int), ("precond", PRECOND_FN), ("precond_user", C.c_void_p)]
+                ("orth", C.c_int), ("initially_zero", C.c_int), ("precond", PRECOND_FN), ("precond_user", C.c_void_p),
+                ("precond_on_device", C.c_int)]
 
 
 class GmresResult(C.Structure):

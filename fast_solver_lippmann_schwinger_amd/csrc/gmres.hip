@@ -73,7 +73,7 @@ static void solve_least_squares(const std::vector<zc>& H, int ldh, double beta, 
 
 void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap, lsfc_gmres_result* res) {
     lsfc_gmres_opts o;
-    if (opts_in) o = *opts_in; else { o.restart = 0; o.maxiter = 0; o.reltol = -1; o.abstol = 0; o.orth = LSFC_ORTH_MGS; o.initially_zero = 0; o.precond = nullptr; o.precond_user = nullptr; }
+    if (opts_in) o = *opts_in; else { o.restart = 0; o.maxiter = 0; o.reltol = -1; o.abstol = 0; o.orth = LSFC_ORTH_MGS; o.initially_zero = 0; o.precond = nullptr; o.precond_user = nullptr; o.precond_on_device = 0; }
     const int64_t N = p->N;
     const int restart = (int)(o.restart > 0 ? o.restart : std::min<int64_t>(20, N));
     const int64_t maxiter = o.maxiter > 0 ? o.maxiter : N;
@@ -82,7 +82,7 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
     LSFC_REQUIRE(o.orth == LSFC_ORTH_MGS || o.orth == LSFC_ORTH_CGS || o.orth == LSFC_ORTH_DGKS, "unknown orthogonalisation %d", o.orth);
     LSFC_REQUIRE(restart >= 1, "restart must be >= 1");
 
-    GmresWorkspace* w = workspace(p, restart, o.precond != nullptr);
+    GmresWorkspace* w = workspace(p, restart, o.precond != nullptr && !o.precond_on_device);
     hipStream_t st = p->stream;
     auto Vcol = [&](int j) { return w->V.p + (size_t)j * (size_t)N; };
     // slab-distributed plan: every inner product / squared norm is completed by an all-reduce over the ranks
@@ -92,6 +92,11 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
 
     auto precondition = [&](cplx* v) {
         if (!o.precond) return;
+        if (o.precond_on_device) {
+            const int rc = o.precond(o.precond_user, (double*)v, N);
+            if (rc != 0) fail(LSFC_EINVAL, "preconditioner callback returned %d", rc);
+            return;
+        }
         LSFC_HIP(hipMemcpyAsync(w->vpin, v, (size_t)N * sizeof(cplx), hipMemcpyDeviceToHost, st));
         LSFC_HIP(hipStreamSynchronize(st));
         const int rc = o.precond(o.precond_user, (double*)w->vpin, N);

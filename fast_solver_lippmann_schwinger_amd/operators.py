@@ -328,15 +328,29 @@ class ConvergenceHistory:
         return self.data[key.lstrip(":")]
 
 
+class _DevPtr:
+    """Minimal __cuda_array_interface__ carrier so torch can alias a raw device pointer (complex128 vector)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<c16", "data": (ptr, False), "version": 2}
+
+
+def _device_view(ptr, n):
+    import torch
+    return torch.as_tensor(_DevPtr(ptr, n), device="cuda")
+
+
 _ORTH = {"ModifiedGramSchmidt": L.LSFC_ORTH_MGS, "ClassicalGramSchmidt": L.LSFC_ORTH_CGS, "DGKS": L.LSFC_ORTH_DGKS}
 
 
 def gmres_(x, A, b, Pl=None, abstol=0.0, reltol=None, restart=None, maxiter=None, log=False,
-           initially_zero=False, orth_meth="ModifiedGramSchmidt"):
+           initially_zero=False, orth_meth="ModifiedGramSchmidt", Pl_on_device=False):
     """gmres!(x, A, b; Pl, abstol, reltol, restart, maxiter, log, initially_zero, orth_meth).
 
     ``Pl`` is a callable ``v -> None`` that overwrites the host numpy vector v with Pl \\ v -- the
-    two-argument in-place ``ldiv!(Pl, v)`` of src/preconditioner.jl:147-170.  x is updated in place."""
+    two-argument in-place ``ldiv!(Pl, v)`` of src/preconditioner.jl:147-170.  x is updated in place.
+    ``Pl_on_device=True``: Pl instead receives a torch CUDA tensor aliasing the Krylov vector on the device (no PCIe
+    round trip) and must work on torch's current stream."""
     N = A.N
     px, sx, keepx = _vec(x, N, "x", plan=A._plan)
     pb, sb, keepb = _vec(b, N, "b")
@@ -355,6 +369,9 @@ def gmres_(x, A, b, Pl=None, abstol=0.0, reltol=None, restart=None, maxiter=None
     if Pl is not None:
         def _cb(user, v, n):
             try:
+                if Pl_on_device:
+                    Pl(_device_view(C.cast(v, C.c_void_p).value, n))
+                    return 0
                 arr = np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_double)), shape=(2 * n,)).view(np.complex128)
                 Pl(arr)
                 return 0
@@ -363,6 +380,7 @@ def gmres_(x, A, b, Pl=None, abstol=0.0, reltol=None, restart=None, maxiter=None
                 return 1
         cb = L.PRECOND_FN(_cb)
         opts.precond = cb
+        opts.precond_on_device = 1 if Pl_on_device else 0
     cap = int(maxiter) if maxiter is not None else N
     cap = max(1, min(cap, 1 << 20))
     res = L.GmresResult()

@@ -157,6 +157,10 @@ typedef struct lsfc_gmres_opts {
     int     orth;          /* LSFC_ORTH_*                            */
     int     initially_zero;/* skip the initial A*x0 (x0 == 0)        */
     lsfc_precond_fn precond; void* precond_user;  /* NULL: Identity() */
+    int     precond_on_device; /* 0 (default): v is a HOST pointer (copied over PCIe around the call, like the
+                                  reference's host-side ldiv!).  1: v is the DEVICE pointer of the Krylov vector
+                                  itself; the callback must enqueue its work on the plan's stream (or synchronise)
+                                  -- the hook for a device-resident preconditioner, no PCIe traffic. */
 } lsfc_gmres_opts;
 
 typedef struct lsfc_gmres_result {

@@ -110,7 +110,7 @@ sampleGConv(k, X, Y, indS, M::FastMHIP) = sampleG3D(k, X, Y, nothing, indS, M)
 # (src/preconditioner.jl:147-170), passed through @cfunction.
 struct GmresOpts
     restart::Cint; maxiter::Int64; reltol::Float64; abstol::Float64; orth::Cint; initially_zero::Cint
-    precond::Ptr{Cvoid}; precond_user::Ptr{Cvoid}
+    precond::Ptr{Cvoid}; precond_user::Ptr{Cvoid}; precond_on_device::Cint
 end
 struct GmresResult
     iters::Int64; mvps::Int64; converged::Cint; final_resnorm::Float64
@@ -124,7 +124,7 @@ function gmres_hip!(x::Vector{Complex{Float64}}, M::FastMHIP, b::Vector{Complex{
                     maxiter=length(b), reltol=sqrt(eps(Float64)), abstol=0.0, initially_zero=false)
     box = Ref{Any}(Pl)
     cb = Pl === nothing ? C_NULL : @cfunction(_precond_trampoline, Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64))
-    opts = Ref(GmresOpts(restart, maxiter, reltol, abstol, 0, initially_zero ? 1 : 0, cb, Pl === nothing ? C_NULL : pointer_from_objref(box)))
+    opts = Ref(GmresOpts(restart, maxiter, reltol, abstol, 0, initially_zero ? 1 : 0, cb, Pl === nothing ? C_NULL : pointer_from_objref(box), 0))
     res = Ref(GmresResult(0, 0, 0, 0.0)); resnorm = zeros(Float64, maxiter)
     GC.@preserve box begin
         rc = ccall((:lsfc_gmres, liblsfc), Cint,

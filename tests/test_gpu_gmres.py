@@ -117,3 +117,25 @@ def test_example_drivers_run(lsfc):
         spec.loader.exec_module(mod)
         U, info = mod.main(arg)
         assert info.isconverged and np.isfinite(U).all()
+
+
+def test_gmres_device_resident_preconditioner(lsfc):
+    # the same diagonal Pl applied on the device through the precond_on_device hook: identical iteration, no PCIe traffic
+    import torch
+    c, Mo, M, rhs = _setup(lsfc, "gv16k10")
+    d = 1.0 + Mo.omega**2 * 0.01 * Mo.nu
+    u1 = np.zeros(M.N, complex)
+    u1, h1 = lsfc.gmres_(u1, M, rhs, Pl=lambda v: v.__itruediv__(d), restart=5, reltol=1e-10, log=True)
+    dd = torch.from_numpy(d).cuda()
+    calls = []
+
+    def Pl_dev(v):
+        assert v.is_cuda and v.dtype == torch.complex128 and v.numel() == M.N
+        calls.append(1)
+        v.div_(dd)
+
+    xb = torch.zeros(M.N, dtype=torch.complex128, device="cuda")
+    rb = torch.from_numpy(rhs).cuda()
+    xb, h2 = lsfc.gmres_(xb, M, rb, Pl=Pl_dev, Pl_on_device=True, restart=5, reltol=1e-10, log=True)
+    assert h2.isconverged and h2.iters == h1.iters and len(calls) == h2.mvps + 1
+    assert rel_err(xb.cpu().numpy(), u1) < 1e-12
