@@ -1,6 +1,6 @@
 """Randomised cross-check of the pipelines (GPU): random grid shapes, symbols, contrasts and flags; the pruned HIP
 pipeline, the rocFFT-reduced and rocFFT-literal pipelines, the simulated distributed ranks and the CPU oracle must agree.
-usage: python tools/stress.py [seconds]"""
+usage: python tests/stress_gpu.py [seconds]   (not collected by pytest; lives under tests/ because it uses the oracle)"""
 import os
 import sys
 import time
