@@ -36,7 +36,7 @@ static int64_t block_elems(const lsfc_plan* p) { return (int64_t)p->dist->Wc * p
 static void phase1(lsfc_plan* p, const cplx* x, bool use_nu, hipStream_t st) {
     const DistState* d = p->dist.get();
     // chunk width Wc: storage index s of a line lands in block s / Wc = dest_rank * K + chunk
-    pruned_xfwd(p->pads[0], p->tuning, x, use_nu ? p->nu.p : nullptr, d->S1.p, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, d->Wc, st);
+    pruned_xfwd(p->pads[0], p->tuning, x, use_nu ? p->nu.p : nullptr, d->S1.p, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, d->Wc, p->dims[0], st);
 }
 static void phase2_yfwd(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
@@ -49,7 +49,7 @@ static void phase2_zfused(lsfc_plan* p, int c, hipStream_t st) {
     const int Ly = p->pads[1], Lz = p->pads[2], l = p->dims[2];
     pruned_zfused(Lz, p->tuning, p->A2.p + (int64_t)c * d->Wc * Ly * l, p->sym.p + (int64_t)c * d->Wc * p->sym_rows * p->sym_hz, p->tw[2].p, d->Wc, Ly,
                   (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p,
-                  p->zmirror.p, st);
+                  p->zmirror.p, l, st);
 }
 static void phase2_yinv(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
@@ -60,7 +60,7 @@ static void phase2_yinv(lsfc_plan* p, int c, hipStream_t st) {
 static void phase2(lsfc_plan* p, int c, hipStream_t st) { phase2_yfwd(p, c, st); phase2_zfused(p, c, st); phase2_yinv(p, c, st); }
 static void phase3(lsfc_plan* p, const cplx* x, cplx* y, double alpha, double beta, hipStream_t st) {
     const DistState* d = p->dist.get();
-    pruned_xinv(p->pads[0], p->tuning, d->S1.p, x, y, alpha, beta, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, d->Wc, st);
+    pruned_xinv(p->pads[0], p->tuning, d->S1.p, x, y, alpha, beta, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, d->Wc, p->dims[0], st);
 }
 
 // Exchange of chunk c.  way in : S1 block (q*K + c)  -> rank q, lands in R1 chunk c at slot <source rank>

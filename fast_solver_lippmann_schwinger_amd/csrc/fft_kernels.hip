@@ -12,6 +12,8 @@
 //   xinv   A1, x                       -> y[n][m][l]
 //
 // (2D: xfwd -> zfused along y on the natural A1[Lx][m] -> xinv.)
+// The grid sizes n, m, l need not be powers of two: every pass reads only the first n (m, l) entries of a line
+// and zero-fills up to L/2, writes only the first n (m, l) on the way back; L = 2*nextpow2(n) per axis.
 // Frequency-side indices are "storage" indices (fft_core.hpp); A2 is tiled so that
 // the eight x'-neighbours of a z-line are interleaved (xi fastest), which makes
 // the largest pass (z: 16 of the 35 complex per point) a pure stream.
@@ -27,10 +29,10 @@ static constexpr int XB = 8;           // x' lines per strided workgroup: 8 * 16
 template <class C, int LPW, bool SPLIT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __restrict__ out,
-            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp) {
+            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp, int n) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int T = C::T, E = C::E, n = C::L / 2;
+    constexpr int T = C::T, E = C::E;
     const int t = threadIdx.x % T, ll = threadIdx.x / T;
     const int64_t line = (int64_t)blockIdx.x * LPW + ll;
     const bool valid = line < nlines;
@@ -38,11 +40,11 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
     const cplx* xin = x + lc * n;
     cplx v[E];
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) v[e] = xin[t + T * e];
+    for (int e = 0; e < E / 2; ++e) v[e] = (t + T * e < n) ? xin[t + T * e] : make_double2(0.0, 0.0);
     if (nu) {
         const double* nin = nu + lc * n;
 #pragma unroll
-        for (int e = 0; e < E / 2; ++e) { const double s = nin[t + T * e]; v[e].x *= s; v[e].y *= s; }
+        for (int e = 0; e < E / 2; ++e) { const double s = (t + T * e < n) ? nin[t + T * e] : 0.0; v[e].x *= s; v[e].y *= s; }
     }
 #pragma unroll
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
@@ -62,10 +64,10 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
 template <class C, int LPW, bool SPLIT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alpha, double beta,
-            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp) {
+            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp, int n) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int T = C::T, E = C::E, n = C::L / 2;
+    constexpr int T = C::T, E = C::E;
     const int t = threadIdx.x % T, ll = threadIdx.x / T;
     const int64_t line = (int64_t)blockIdx.x * LPW + ll;
     const bool valid = line < nlines;
@@ -81,10 +83,12 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
     if (valid) {
 #pragma unroll
         for (int e = 0; e < E / 2; ++e) {
-            const int64_t idx = line * n + t + T * e;
-            cplx r = make_double2(beta * v[e].x, beta * v[e].y);
-            if (alpha != 0.0) { const cplx xo = xorig[idx]; r.x = fma(alpha, xo.x, r.x); r.y = fma(alpha, xo.y, r.y); }
-            y[idx] = r;
+            if (t + T * e < n) {
+                const int64_t idx = line * n + t + T * e;
+                cplx r = make_double2(beta * v[e].x, beta * v[e].y);
+                if (alpha != 0.0) { const cplx xo = xorig[idx]; r.x = fma(alpha, xo.x, r.x); r.y = fma(alpha, xo.y, r.y); }
+                y[idx] = r;
+            }
         }
     }
 }
@@ -107,7 +111,7 @@ void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __re
     const cplx* src = a1 + xp + (int64_t)p1 * m * z;
     cplx v[E];
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) v[e] = src[(int64_t)p1 * (t + T * e)];
+    for (int e = 0; e < E / 2; ++e) v[e] = (t + T * e < m) ? src[(int64_t)p1 * (t + T * e)] : make_double2(0.0, 0.0);
 #pragma unroll
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
     fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
@@ -139,7 +143,7 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
     fft_inverse<C, LL, true>(v, t, tw, smem, 0, xi);
     cplx* dst = a1 + xp + (int64_t)p1 * m * z;
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) dst[(int64_t)p1 * (t + T * e)] = v[e];
+    for (int e = 0; e < E / 2; ++e) if (t + T * e < m) dst[(int64_t)p1 * (t + T * e)] = v[e];
 }
 
 // In-place forward -> .* sym -> inverse along one strided axis.
@@ -163,7 +167,7 @@ template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF = fa
 __global__ __launch_bounds__(C::T * LINES, WPE)
 void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
               int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
-              const int2* __restrict__ ytab, const int* __restrict__ zm) {
+              const int2* __restrict__ ytab, const int* __restrict__ zm, int nin) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -184,7 +188,7 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
     const int li = threadIdx.x % LINES;                 // line slot inside this workgroup's LDS
     cplx v[E];
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) v[e] = d[dLine * (t + T * e)];
+    for (int e = 0; e < E / 2; ++e) v[e] = (t + T * e < nin) ? d[dLine * (t + T * e)] : make_double2(0.0, 0.0);
 #pragma unroll
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
     if constexpr (ZE) {
@@ -229,7 +233,7 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
     }
     fft_inverse<C, LL, true>(v, t, tw, smem, 0, li);
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) d[dLine * (t + T * e)] = v[e];
+    for (int e = 0; e < E / 2; ++e) if (t + T * e < nin) d[dLine * (t + T * e)] = v[e];
 }
 
 // ---------------------------------------------------------------------------
@@ -247,21 +251,21 @@ template <class C> struct Tune {
     static constexpr int LINES = (C::T * XB <= 512 || (C::E <= 8 && C::T * XB <= 1024)) ? XB : 512 / C::T;
 };
 
-template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int logW, int Wp, hipStream_t st) {
+template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int logW, int Wp, int n, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = k_xfwd<C, LPW, SPLIT>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW, Wp);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW, Wp, n);
 }
-template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int logW, int Wp, hipStream_t st) {
+template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int logW, int Wp, int n, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = k_xinv<C, LPW, SPLIT>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW, Wp);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW, Wp, n);
 }
 static void ytile(const PrunedTuning& tn, int L, int ngrp, int l, int& TG, int& TZ) {
     // auto (0): all groups x 1 plane, except at L >= 1024 where 32 groups x 8 planes keeps the 128-B chunks that the
@@ -290,7 +294,7 @@ template <class C, bool SPLIT, int WPE> static void yinv_t(const PrunedTuning& t
 }
 template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                                                     int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                                                    const int2* ytab, const int* zm, hipStream_t st) {
+                                                    const int2* ytab, const int* zm, int nin, hipStream_t st) {
     // dTile/sTile are strides per XB-tile of x'; a workgroup covers LINES of the XB lines of a tile.
     constexpr int LINES = Tune<C>::LINES;
     static_assert(XB % LINES == 0, "LINES must divide XB");
@@ -300,20 +304,20 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     allow_lds(k, lds);
     if (LINES == XB) {
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / XB) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm);
+                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin);
     } else {
         // split each tile into XB/LINES sub-groups: sub-group h starts at xi offset h*LINES
         // (tile, sub-group) collapse to one group index only when tiles are XB-contiguous in xi (2D natural layout)
         LSFC_REQUIRE(dTile == XB && sTile == XB, "sub-tile groups need the natural (2D) layout");
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab, zm);
+                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab, zm, nin);
     }
 }
 
 // half-tile z pass (L = 1024 in 3D tiled layout only): 4-line workgroups, sibling halves 8 blocks apart
 template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static void zfused_half_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                                                          int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                                                         const int2* ytab, const int* zm, hipStream_t st) {
+                                                         const int2* ytab, const int* zm, int nin, hipStream_t st) {
     constexpr int LINES = 4;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
@@ -322,7 +326,7 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     const int64_t ntiles = (int64_t)(Lx / XB) * nouter;
     LSFC_REQUIRE(ntiles % 8 == 0, "half-tile z pass needs a multiple of 8 tiles");
     hipLaunchKernelGGL(k, dim3((unsigned)(2 * ntiles)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm);
+                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin);
 }
 
 static bool env_flag(const char* name, bool dflt) {
@@ -366,16 +370,16 @@ PrunedTuning pruned_default_tuning() {
 
 static int log2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; LSFC_REQUIRE((1 << l) == v, "chunk width %d is not a power of two", v); return l; }
 
-void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, hipStream_t st) {
+void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st) {
     const int logW = log2_exact(W);
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, logW, Wp, st))); }
-    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, logW, Wp, st))); }
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, logW, Wp, n, st))); }
+    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, logW, Wp, n, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, hipStream_t st) {
+void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st) {
     const int logW = log2_exact(W);
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, st))); }
-    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, st))); }
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, n, st))); }
+    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, n, st))); }
     LSFC_HIP(hipGetLastError());
 }
 void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
@@ -390,16 +394,16 @@ void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const 
 }
 void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, const int2* ytab,
-                   const int* zm, hipStream_t st) {
-#define LSFC_ZF(SP, PF) do { if (zm) { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st))); } \
-                             else    { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st))); } } while (0)
+                   const int* zm, int nin, hipStream_t st) {
+#define LSFC_ZF(SP, PF) do { if (zm) { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); } \
+                             else    { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); } } while (0)
     // auto (-1): half-tile, split exchanges, symbol prefetch -- 6.95 -> 6.6 ms at 512^3 (profiles/r01_experiment_half_tile.log)
     // with the z-even half symbol the full-tile form wins (6.05 ms, profiles/r01_experiment_even_z.log)
     const int zh = tn.z_half >= 0 ? tn.z_half : (zm ? 0 : 2);
     if (L == 1024 && zh > 0 && dLine == 8 && ((int64_t)(Lx / XB) * nouter) % 8 == 0) {
         using C = Cfg1024;
-#define LSFC_ZH(SP, PF, W) do { if (zm) zfused_half_t<C, SP, PF, W, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st); \
-                                else zfused_half_t<C, SP, PF, W, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, st); } while (0)
+#define LSFC_ZH(SP, PF, W) do { if (zm) zfused_half_t<C, SP, PF, W, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st); \
+                                else zfused_half_t<C, SP, PF, W, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st); } while (0)
         switch (zh) {
         case 1: LSFC_ZH(false, true, 2); break;
         case 2: LSFC_ZH(true, true, 2); break;

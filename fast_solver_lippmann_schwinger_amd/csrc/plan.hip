@@ -106,10 +106,31 @@ static void make_twiddles(lsfc_plan* p, int axis, int L) {
     LSFC_HIP(hipMemcpy(p->tw[axis].p, tw.data(), (size_t)L * sizeof(cplx), hipMemcpyHostToDevice));
 }
 
+static int next_pow2(int v) { int p2 = 1; while (p2 < v) p2 <<= 1; return p2; }
+
+// The hand-written pipeline works on L = 2*nextpow2(n) per axis (the grid itself may have any size: lines are
+// zero-extended in registers).  It is chosen unless the power-of-two embedding would more than quadruple the
+// number of grid points, where the monolithic rocFFT transform on the exact 2n grid is the better deal.
 static bool pruned_eligible(const lsfc_plan* p) {
     if (p->flags & (LSFC_FLAG_FORCE_ROCFFT | LSFC_FLAG_LITERAL_PAD)) return false;
-    for (int d = 0; d < p->ndim; ++d) if (!pruned_length_supported(2 * (int64_t)p->dims[d])) return false;
-    return true;
+    double ratio = 1.0;
+    for (int d = 0; d < p->ndim; ++d) {
+        const int n2 = std::max(16, next_pow2(p->dims[d]));
+        if (!pruned_length_supported(2 * (int64_t)n2)) return false;
+        ratio *= (double)n2 / (double)p->dims[d];
+    }
+    return ratio <= 4.0;
+}
+
+// working padded grid of the reduced pipelines: 2*nextpow2(n) (pruned) or 2n (rocFFT)
+void plan_choose_reduced_grid(lsfc_plan* p) {
+    const bool pr = pruned_eligible(p);
+    for (int d = 0; d < 3; ++d) {
+        p->crop[d] = 0;
+        if (d >= p->ndim) p->pads[d] = 1;
+        else p->pads[d] = pr ? 2 * std::max(16, next_pow2(p->dims[d])) : 2 * p->dims[d];
+    }
+    p->pipeline = pr ? lsfc_plan::PRUNED : lsfc_plan::ROCFFT_REDUCED;
 }
 
 static void setup_rocfft_pipeline(lsfc_plan* p) {
@@ -189,10 +210,11 @@ void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>
 }
 
 void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
-    for (int d = 0; d < 3; ++d) { p->pads[d] = (d < p->ndim) ? 2 * p->dims[d] : 1; p->crop[d] = 0; }
+    // G2: natural FFT-order symbol on the grid chosen by plan_choose_reduced_grid
     const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
+    LSFC_REQUIRE((int64_t)G2.n == total, "internal: reduced symbol has %lld entries, grid has %lld", (long long)G2.n, (long long)total);
     const double scale = 1.0 / (double)total;
-    if (pruned_eligible(p)) {
+    if (p->pipeline == lsfc_plan::PRUNED) {
         std::vector<int> perm[3];
         DevBuf<int> dperm[3];
         for (int d = 0; d < p->ndim; ++d) {
@@ -222,22 +244,24 @@ void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
         p->pitch2 = 8 * p->dims[2] + pad2 / 8 * 8;
         p->A1.alloc((size_t)p->pitch1 * p->dims[1] * p->dims[2]);
         if (p->ndim == 3) p->A2.alloc((size_t)p->pitch2 * p->pads[1] * (p->pads[0] / 8));
-        p->pipeline = lsfc_plan::PRUNED;
     } else {
         pw_scale(G2.p, scale, total, p->stream);
         LSFC_HIP(hipStreamSynchronize(p->stream));
         p->sym = std::move(G2);
-        p->pipeline = lsfc_plan::ROCFFT_REDUCED;
         setup_rocfft_pipeline(p);
     }
 }
 
-void plan_finish_reduce(lsfc_plan* p, DevBuf<cplx>& Gd, const int lit[3], bool centred) {
-    // T = ifft(ifftshift(G)) on the literal grid, keep offsets -n..n-1 per axis, G2 = fft(T2)
+void plan_finish_reduce(lsfc_plan* p, DevBuf<cplx>& Gd, const int lit[3], bool centred, const int kernel_origin[3]) {
+    // T = ifft(ifftshift(G)) on the literal grid is the spatial kernel; the cropped convolution only needs its
+    // offsets -(n-1)..n-1 per axis, so it is re-sampled on the working grid q and transformed back: G2 = fft(T2).
+    //   Greengard-Vico: offset d sits at index d mod lit (kernel_origin = 0), crop window [0, n).
+    //   trapezoidal:    offset d sits at index d + (n-1) (kernel_origin = n-1; crop window [n-1, 2n-2] of the reference).
+    plan_choose_reduced_grid(p);
+    const int* q = p->pads;
     for (int d = 0; d < p->ndim; ++d)
-        LSFC_REQUIRE(lit[d] >= 2 * p->dims[d], "padded size %d along axis %d is smaller than 2n=%d", lit[d], d, 2 * p->dims[d]);
+        LSFC_REQUIRE(lit[d] >= 2 * p->dims[d] - 1, "padded size %d along axis %d is smaller than 2n-1=%d", lit[d], d, 2 * p->dims[d] - 1);
     const int64_t ltotal = (int64_t)lit[0] * lit[1] * lit[2];
-    int q[3]; for (int d = 0; d < 3; ++d) q[d] = (d < p->ndim) ? 2 * p->dims[d] : 1;
     const int64_t qtotal = (int64_t)q[0] * q[1] * q[2];
     {
         DevBuf<cplx> tmp; tmp.alloc((size_t)ltotal);
@@ -249,7 +273,8 @@ void plan_finish_reduce(lsfc_plan* p, DevBuf<cplx>& Gd, const int lit[3], bool c
         RocFft inv; inv.create(3, len, false);
         inv.exec(tmp.p, p->stream);
         Gd.alloc((size_t)qtotal);
-        pw_wrap_crop(tmp.p, Gd.p, lit, q, 1.0 / (double)ltotal, p->stream);
+        int nmax[3]; for (int d = 0; d < 3; ++d) nmax[d] = (d < p->ndim) ? p->dims[d] - 1 : 0;
+        pw_resample_kernel(tmp.p, Gd.p, lit, q, kernel_origin, nmax, 1.0 / (double)ltotal, p->stream);
         LSFC_HIP(hipStreamSynchronize(p->stream));
     }
     {
@@ -272,18 +297,18 @@ void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
         const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
         const int m = p->dims[1], l = p->dims[2];
         const int64_t nlines = (int64_t)m * l;
-        pruned_xfwd(Lx, p->tuning, x, nu, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, st);
+        pruned_xfwd(Lx, p->tuning, x, nu, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st);
         if (p->ndim == 3) {
             const int p1 = p->pitch1, p2 = p->pitch2;
             pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, p1, p2, st);
             pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
                           (int64_t)p2 * Ly, (int64_t)p2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p,
-                          p->zmirror.p, st);
+                          p->zmirror.p, l, st);
             pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p1, p2, st);
         } else {
-            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, st);
+            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, m, st);
         }
-        pruned_xinv(Lx, p->tuning, p->A1.p, x, y, alpha, beta, p->tw[0].p, nlines, Lx, p->pitch1, st);
+        pruned_xinv(Lx, p->tuning, p->A1.p, x, y, alpha, beta, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st);
     } else {
         const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
         pw_embed(x, nu, p->W.p, p->dims, p->pads, st);
@@ -344,18 +369,16 @@ static int create_from_literal(lsfc_plan** out, int ndim, int64_t n, int64_t m, 
         const int64_t ltotal = ne * me * le;
         DevBuf<cplx> Gd; Gd.alloc((size_t)ltotal);
         LSFC_HIP(hipMemcpy(Gd.p, gfft, (size_t)ltotal * sizeof(cplx), hipMemcpyHostToDevice));
-        if (quad_rule == LSFC_QUAD_TRAPEZOIDAL) {
-            // plain FFT-order symbol on the (2n-1) grid, crop window [n-1, 2n-2] (src/FastConvolution.jl:70-82)
-            for (int d = 0; d < ndim; ++d)
-                LSFC_REQUIRE(lit[d] >= 2 * p->dims[d] - 1, "trapezoidal: padded size %d < 2n-1 along axis %d", lit[d], d);
-            for (int d = 0; d < 3; ++d) { p->pads[d] = lit[d]; p->crop[d] = (d < ndim) ? p->dims[d] - 1 : 0; }
-            plan_finish_literal(p.get(), Gd.p, false);
-        } else if (flags & LSFC_FLAG_LITERAL_PAD) {
-            for (int d = 0; d < ndim; ++d) LSFC_REQUIRE(lit[d] >= p->dims[d], "padded size smaller than the grid");
-            for (int d = 0; d < 3; ++d) { p->pads[d] = lit[d]; p->crop[d] = 0; }
-            plan_finish_literal(p.get(), Gd.p, true);
+        const bool trap = quad_rule == LSFC_QUAD_TRAPEZOIDAL;
+        // trapezoidal: plain FFT-order symbol on the (2n-1) grid, crop window [n-1, 2n-2] (src/FastConvolution.jl:70-82)
+        for (int d = 0; d < ndim; ++d)
+            LSFC_REQUIRE(lit[d] >= (trap ? 2 * p->dims[d] - 1 : p->dims[d]), "padded size %d too small along axis %d", lit[d], d);
+        int origin[3]; for (int d = 0; d < 3; ++d) origin[d] = (trap && d < ndim) ? p->dims[d] - 1 : 0;
+        if (flags & LSFC_FLAG_LITERAL_PAD) {
+            for (int d = 0; d < 3; ++d) { p->pads[d] = lit[d]; p->crop[d] = origin[d]; }
+            plan_finish_literal(p.get(), Gd.p, !trap);
         } else {
-            plan_finish_reduce(p.get(), Gd, lit, true);
+            plan_finish_reduce(p.get(), Gd, lit, !trap, origin);
         }
         *out = p.release();
     });
@@ -379,6 +402,7 @@ int lsfc_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, doub
         std::unique_ptr<lsfc_plan> p(new lsfc_plan());
         plan_common_init(p.get(), 3, n, m, l, nu, omega, LSFC_QUAD_GREENGARD_VICO, flags & ~LSFC_FLAG_LITERAL_PAD, device);
         DevBuf<cplx> G2;
+        plan_choose_reduced_grid(p.get());
         symbol_gv3d_reduced(p.get(), box, G2);
         plan_finish_from_reduced(p.get(), G2);
         *out = p.release();
@@ -393,10 +417,11 @@ int lsfc_plan_create_gv2d(lsfc_plan** out, int64_t n, int64_t m, double box, dou
         plan_common_init(p.get(), 2, n, m, 1, nu, omega, LSFC_QUAD_GREENGARD_VICO, flags, device);
         DevBuf<cplx> G; int lit[3];
         symbol_gv2d_literal(p.get(), box, G, lit);
+        const int origin[3] = { 0, 0, 0 };
         if (flags & LSFC_FLAG_LITERAL_PAD) {
             for (int d = 0; d < 3; ++d) { p->pads[d] = lit[d]; p->crop[d] = 0; }
             plan_finish_literal(p.get(), G.p, true);
-        } else plan_finish_reduce(p.get(), G, lit, true);
+        } else plan_finish_reduce(p.get(), G, lit, true, origin);
         *out = p.release();
     });
 }
@@ -410,9 +435,12 @@ int lsfc_plan_create_trap2d(lsfc_plan** out, int64_t n, int64_t m, double x0, do
         plan_common_init(p.get(), 2, n, m, 1, nu, omega, LSFC_QUAD_TRAPEZOIDAL, flags, device);
         DevBuf<cplx> G;
         symbol_trap2d_literal(p.get(), x0, y0, h, make_double2(d0_re, d0_im), G);
-        p->pads[0] = 2 * (int)n - 1; p->pads[1] = 2 * (int)m - 1; p->pads[2] = 1;
-        p->crop[0] = (int)n - 1; p->crop[1] = (int)m - 1; p->crop[2] = 0;
-        plan_finish_literal(p.get(), G.p, false);
+        const int lit[3] = { 2 * (int)n - 1, 2 * (int)m - 1, 1 };
+        const int origin[3] = { (int)n - 1, (int)m - 1, 0 };
+        if (flags & LSFC_FLAG_LITERAL_PAD) {
+            for (int d = 0; d < 3; ++d) { p->pads[d] = lit[d]; p->crop[d] = origin[d]; }
+            plan_finish_literal(p.get(), G.p, false);
+        } else plan_finish_reduce(p.get(), G, lit, false, origin);
         *out = p.release();
     });
 }
@@ -596,17 +624,17 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
             const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
             const int m = p->dims[1], l = p->dims[2];
             const int64_t nlines = (int64_t)m * l;
-            stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, [=] { pruned_xfwd(Lx, p->tuning, x, p->nu.p, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, st); }});
+            stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, [=] { pruned_xfwd(Lx, p->tuning, x, p->nu.p, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st); }});
             if (p->ndim == 3) {
                 stages.push_back({"yfwd", (2 + 4) * N * C, [=] { pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, p->pitch1, p->pitch2, st); }});
                 stages.push_back({"zfused", (4 + 8 + 4) * N * C, [=] { pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
                                   (int64_t)p->pitch2 * Ly, (int64_t)p->pitch2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8,
-                                  p->ytab.p, p->zmirror.p, st); }});
+                                  p->ytab.p, p->zmirror.p, l, st); }});
                 stages.push_back({"yinv", (4 + 2) * N * C, [=] { pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p->pitch1, p->pitch2, st); }});
             } else {
-                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, st); }});
+                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, m, st); }});
             }
-            stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, Lx, p->pitch1, st); }});
+            stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st); }});
         } else {
             const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
             const double P = (double)total;

@@ -98,6 +98,31 @@ __global__ void k_wrap_crop(const cplx* __restrict__ src, cplx* __restrict__ dst
     }
 }
 
+// Re-sample the spatial kernel on the working grid: offset d in [-nmax, nmax] per axis sits at src index
+// (d + origin) mod p and goes to dst index d mod q; every other dst entry (offsets the cropped convolution never
+// touches) is zero.
+__global__ void k_resample_kernel(const cplx* __restrict__ src, cplx* __restrict__ dst, int p0, int p1, int p2, int q0, int q1, int q2,
+                                  int o0, int o1, int o2, int n0, int n1, int n2, double scale) {
+    const int64_t total = (int64_t)q0 * q1 * q2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % q0); const int64_t r = idx / q0; const int j = (int)(r % q1); const int k = (int)(r / q1);
+        const int d0 = (i <= n0) ? i : i - q0, d1 = (j <= n1) ? j : j - q1, d2 = (k <= n2) ? k : k - q2;
+        cplx v = make_double2(0.0, 0.0);
+        if (d0 >= -n0 && d1 >= -n1 && d2 >= -n2) {
+            const int s0 = ((d0 + o0) % p0 + p0) % p0, s1 = ((d1 + o1) % p1 + p1) % p1, s2 = ((d2 + o2) % p2 + p2) % p2;
+            const cplx w = src[s0 + (int64_t)p0 * (s1 + (int64_t)p1 * s2)];
+            v = make_double2(scale * w.x, scale * w.y);
+        }
+        dst[idx] = v;
+    }
+}
+void pw_resample_kernel(const cplx* src, cplx* dst, const int p[3], const int q[3], const int origin[3], const int nmax[3], double scale, hipStream_t st) {
+    const int64_t total = (int64_t)q[0] * q[1] * q[2];
+    hipLaunchKernelGGL(k_resample_kernel, dim3(grid_for(total)), dim3(256), 0, st, src, dst, p[0], p[1], p[2], q[0], q[1], q[2],
+                       origin[0], origin[1], origin[2], nmax[0], nmax[1], nmax[2], scale);
+    LSFC_HIP(hipGetLastError());
+}
+
 // Natural FFT-order symbol G2[Lx][Ly][Lz] -> storage-order, tile-interleaved layout of the
 // pruned pipeline.  3D: out[xi + 8*(sz + Lz*(sy + Ly*xb))];  2D (Lz==1): out[sx + Lx*sy].
 // 3D: `rows` symbol rows per tile; pyrow[r] = y frequency of row r (rows == Ly: every storage row; rows == Ly/2+1:

@@ -11,6 +11,7 @@ void pw_crop_axpy(const cplx* W, const cplx* x, cplx* y, double alpha, double be
                   const int off[3], hipStream_t);
 // symbol preparation
 void pw_roll_scale(const cplx* src, cplx* dst, const int p[3], const int s[3], double scale, hipStream_t);
+void pw_resample_kernel(const cplx* src, cplx* dst, const int p[3], const int q[3], const int origin[3], const int nmax[3], double scale, hipStream_t);
 void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], double scale, hipStream_t);
 // 3D: tiles [xb0, xb0+ntiles) of the x' axis only (the symbol slab of one rank); 2D: whole symbol
 void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int hz, int xb0, int ntiles, double scale, hipStream_t);

@@ -15,21 +15,24 @@ struct PrunedTuning {
 };
 
 bool pruned_length_supported(int64_t L);
+// n (x passes), m (y passes), nin (fused pass): the actual grid size along the transformed axis, <= L/2; entries beyond
+// it are treated as zero on the way in and not written on the way back.
 // W = chunk width of the x'-storage axis in the xfwd output / xinv input: out[s / W][line][s % W] (W = L on one GPU;
 // W = L / nranks packs the slab transpose for free).
 // freq_of_storage[s] = frequency index held at storage index s after the forward pass of length L
 void pruned_perm(int L, int* freq_of_storage);
 PrunedTuning pruned_default_tuning();
 
-void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, hipStream_t);
+void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t);
 void pruned_xinv(int L, const PrunedTuning&, const cplx* in, const cplx* xorig, cplx* y, double alpha, double beta,
-                 const cplx* tw, int64_t nlines, int W, int Wp, hipStream_t);
+                 const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t);
 // p1: row pitch of A1 (>= Lx), p2: pitch of one storage-y row of an A2 tile (>= 8*l); both multiples of 8 elements
 void pruned_yfwd(int L, const PrunedTuning&, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);
 void pruned_yinv(int L, const PrunedTuning&, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);
 void pruned_zfused(int L, const PrunedTuning&, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
                    const int2* ytab /* block order -> (data row, symbol row); NULL: identity */,
-                   const int* zm /* z-even symbol: partner storage index of every upper-half slot; NULL: full symbol lines */, hipStream_t);
+                   const int* zm /* z-even symbol: partner storage index of every upper-half slot; NULL: full symbol lines */,
+                   int nin /* valid entries per line (<= L/2) */, hipStream_t);
 
 } // namespace lsfc

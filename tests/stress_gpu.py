@@ -36,7 +36,10 @@ def main(budget):
     while time.time() < t_end:
         it += 1
         dim = rng.choice([2, 3])
-        sizes = [int(rng.choice([16, 32, 64] if dim == 3 else [16, 32, 64, 128, 256])) for _ in range(dim)]
+        if rng.random() < 0.5:
+            sizes = [int(rng.choice([16, 32, 64] if dim == 3 else [16, 32, 64, 128, 256])) for _ in range(dim)]
+        else:                                          # arbitrary (odd, non-power-of-two) sizes
+            sizes = [int(rng.integers(9, 49 if dim == 3 else 200)) for _ in range(dim)]
         N = int(np.prod(sizes))
         lit = tuple(4 * s for s in sizes)
         G = even_symbol(rng, lit) if rng.random() < 0.5 else (rng.standard_normal(lit) + 1j * rng.standard_normal(lit))
@@ -53,7 +56,8 @@ def main(budget):
                 M = ls.FastM(G, nu, *lit, *sizes, k, quadRule="Greengard_Vico", flags=flags)
             errs[name] = rel(M * b, ref)
             M.close()
-        if dim == 3 and sizes[0] == sizes[1] == sizes[2] or dim == 3:
+        pow2 = all(v & (v - 1) == 0 for v in sizes)
+        if dim == 3 and pow2:
             # builder + simulated ranks against the single-GPU builder (same generated symbol)
             n, m, l = sizes
             h = 1.0 / n

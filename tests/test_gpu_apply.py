@@ -18,8 +18,11 @@ LITERAL, FORCE_ROCFFT, PATCH = 1, 2, 4
 
 # ---------------------------------------------------------------------------- 2D, literal-symbol constructor
 @pytest.mark.parametrize("name,flags,pipeline", [
-    ("trap21", 0, "rocfft-literal"),
-    ("gv33", 0, "rocfft-reduced"),
+    ("trap21", 0, "pruned-hip"),               # odd n: embedded in the next power-of-two working grid (2*32)
+    ("trap21", FORCE_ROCFFT, "rocfft-reduced"),
+    ("trap21", LITERAL, "rocfft-literal"),     # the reference's literal (2n-1) grid and crop window
+    ("gv33", 0, "pruned-hip"),
+    ("gv33", FORCE_ROCFFT, "rocfft-reduced"),
     ("gv33", LITERAL, "rocfft-literal"),
     ("gv32", 0, "pruned-hip"),
     ("gv32", FORCE_ROCFFT, "rocfft-reduced"),
@@ -79,6 +82,41 @@ def test_noncubic_3d_pruned(lsfc):
         assert M.pipeline == pipe
         assert rel_err(M * b, ref) < TOL, pipe
         assert rel_err(lsfc.FFTconvolution(M, b), o.convolve_reduced(G2, b, (n, m, l))) < TOL, pipe
+
+
+@pytest.mark.parametrize("dims", [(24, 20, 18), (48, 16, 30), (17, 33, 19)])
+def test_sizes_that_are_not_powers_of_two_3d(lsfc, dims):
+    # any grid size runs in the hand-written pipeline: lines are zero-extended to L/2 = nextpow2(n) in registers
+    n, m, l = dims
+    rng = np.random.default_rng(sum(dims))
+    G = rng.standard_normal((4 * n, 4 * m, 4 * l)) + 1j * rng.standard_normal((4 * n, 4 * m, 4 * l))
+    nu = rng.uniform(-0.3, 0.3, n * m * l)
+    b = o.random_vector(n * m * l)
+    G2 = o.reduce_symbol(G, (n, m, l))
+    ref = o.apply_reduced(G2, nu, 5.0, b, (n, m, l))
+    M = lsfc.FastM3D(G, nu, 4 * n, 4 * m, 4 * l, n, m, l, 5.0)
+    np2 = [max(16, 1 << (v - 1).bit_length()) for v in dims]
+    if np.prod(np2) <= 4 * n * m * l:      # embedding costs at most 4x the points: hand-written pipeline
+        assert M.pipeline == "pruned-hip" and M.padded_dims == tuple(2 * v for v in np2)
+    else:                                  # (17, 33, 19): 6.1x -> rocFFT on the exact 2n grid
+        assert M.pipeline == "rocfft-reduced" and M.padded_dims == tuple(2 * v for v in dims)
+    assert rel_err(M * b, ref) < TOL
+    assert rel_err(lsfc.FFTconvolution(M, b), o.convolve_reduced(G2, b, (n, m, l))) < TOL
+    Mr = lsfc.FastM3D(G, nu, 4 * n, 4 * m, 4 * l, n, m, l, 5.0, flags=FORCE_ROCFFT)
+    assert Mr.pipeline == "rocfft-reduced" and rel_err(Mr * b, ref) < TOL
+
+
+def test_reference_example_size_n48_builder(lsfc):
+    # examples/example3D.jl uses n = 48 (h = 1/48, k = 48): builder on the device vs the oracle's literal builder
+    n = 48
+    x, h = cases.grid(n, False)
+    k = 1.0 / h
+    X, Y, Z = o.grid3d(x, x, x)
+    M = lsfc.buildFastConvolution3D(x, x, x, X, Y, Z, h, k, o.gaussian_bump)
+    assert M.pipeline == "pruned-hip" and M.padded_dims == (128, 128, 128)
+    Mo = o.build_fast_convolution3d(x, x, x, X, Y, Z, h, k, o.gaussian_bump)
+    b = o.random_vector(n ** 3)
+    assert rel_err(M * b, o.mul(Mo, b)) < TOL
 
 
 def test_noncubic_2d_pruned(lsfc):
