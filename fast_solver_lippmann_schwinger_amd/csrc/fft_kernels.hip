@@ -26,7 +26,8 @@ using namespace fft;
 
 static constexpr int XB = 8;           // x' lines per strided workgroup: 8 * 16 B = one 128-B line
 
-template <class C, int LPW, bool SPLIT>
+// EXACT: n == L/2 (power-of-two grid): the end-of-line predicates compile away
+template <class C, int LPW, bool SPLIT, bool EXACT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __restrict__ out,
             const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp, int n) {
@@ -40,11 +41,11 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
     const cplx* xin = x + lc * n;
     cplx v[E];
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) v[e] = (t + T * e < n) ? xin[t + T * e] : make_double2(0.0, 0.0);
+    for (int e = 0; e < E / 2; ++e) v[e] = (EXACT || t + T * e < n) ? xin[t + T * e] : make_double2(0.0, 0.0);
     if (nu) {
         const double* nin = nu + lc * n;
 #pragma unroll
-        for (int e = 0; e < E / 2; ++e) { const double s = (t + T * e < n) ? nin[t + T * e] : 0.0; v[e].x *= s; v[e].y *= s; }
+        for (int e = 0; e < E / 2; ++e) { const double s = (EXACT || t + T * e < n) ? nin[t + T * e] : 0.0; v[e].x *= s; v[e].y *= s; }
     }
 #pragma unroll
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
@@ -61,7 +62,7 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
     }
 }
 
-template <class C, int LPW, bool SPLIT>
+template <class C, int LPW, bool SPLIT, bool EXACT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alpha, double beta,
             const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp, int n) {
@@ -83,7 +84,7 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
     if (valid) {
 #pragma unroll
         for (int e = 0; e < E / 2; ++e) {
-            if (t + T * e < n) {
+            if (EXACT || t + T * e < n) {
                 const int64_t idx = line * n + t + T * e;
                 cplx r = make_double2(beta * v[e].x, beta * v[e].y);
                 if (alpha != 0.0) { const cplx xo = xorig[idx]; r.x = fma(alpha, xo.x, r.x); r.y = fma(alpha, xo.y, r.y); }
@@ -94,7 +95,7 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
 }
 
 // A1[Lx][m][l] (natural) -> A2[XB][l][Ly][Lx/XB]
-template <class C, int LINES, bool SPLIT, int WPE>
+template <class C, int LINES, bool SPLIT, int WPE, bool EXACT>
 __global__ __launch_bounds__(C::T * LINES, WPE)
 void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ, int p1, int p2) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
@@ -111,7 +112,7 @@ void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __re
     const cplx* src = a1 + xp + (int64_t)p1 * m * z;
     cplx v[E];
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) v[e] = (t + T * e < m) ? src[(int64_t)p1 * (t + T * e)] : make_double2(0.0, 0.0);
+    for (int e = 0; e < E / 2; ++e) v[e] = (EXACT || t + T * e < m) ? src[(int64_t)p1 * (t + T * e)] : make_double2(0.0, 0.0);
 #pragma unroll
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
     fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
@@ -121,7 +122,7 @@ void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __re
     for (int e = 0; e < E; ++e) dst[(int64_t)p2 * (t + T * e)] = v[e];
 }
 
-template <class C, int LINES, bool SPLIT, int WPE>
+template <class C, int LINES, bool SPLIT, int WPE, bool EXACT>
 __global__ __launch_bounds__(C::T * LINES, WPE)
 void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ, int p1, int p2) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
@@ -143,7 +144,7 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
     fft_inverse<C, LL, true>(v, t, tw, smem, 0, xi);
     cplx* dst = a1 + xp + (int64_t)p1 * m * z;
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) if (t + T * e < m) dst[(int64_t)p1 * (t + T * e)] = v[e];
+    for (int e = 0; e < E / 2; ++e) if (EXACT || t + T * e < m) dst[(int64_t)p1 * (t + T * e)] = v[e];
 }
 
 // In-place forward -> .* sym -> inverse along one strided axis.
@@ -163,7 +164,7 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
 // (exactly the slots e < E/2 of every thread) plus the kz = L/2 entry at index L/2.  Each thread loads its E/2
 // values; the mirror values (kz -> L - kz) of its slots e >= E/2 are held by other threads of the same line and are
 // fetched through LDS (zm[s - L/2] = storage index of the partner).  Halves the symbol bytes of the pass again.
-template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF = false, bool ZE = false>
+template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF, bool ZE, bool EXACT>
 __global__ __launch_bounds__(C::T * LINES, WPE)
 void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
               int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
@@ -188,7 +189,7 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
     const int li = threadIdx.x % LINES;                 // line slot inside this workgroup's LDS
     cplx v[E];
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) v[e] = (t + T * e < nin) ? d[dLine * (t + T * e)] : make_double2(0.0, 0.0);
+    for (int e = 0; e < E / 2; ++e) v[e] = (EXACT || t + T * e < nin) ? d[dLine * (t + T * e)] : make_double2(0.0, 0.0);
 #pragma unroll
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
     if constexpr (ZE) {
@@ -233,7 +234,7 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
     }
     fft_inverse<C, LL, true>(v, t, tw, smem, 0, li);
 #pragma unroll
-    for (int e = 0; e < E / 2; ++e) if (t + T * e < nin) d[dLine * (t + T * e)] = v[e];
+    for (int e = 0; e < E / 2; ++e) if (EXACT || t + T * e < nin) d[dLine * (t + T * e)] = v[e];
 }
 
 // ---------------------------------------------------------------------------
@@ -255,7 +256,7 @@ template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* n
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
-    auto k = k_xfwd<C, LPW, SPLIT>;
+    auto k = (n == C::L / 2) ? k_xfwd<C, LPW, SPLIT, true> : k_xfwd<C, LPW, SPLIT, false>;
     allow_lds(k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW, Wp, n);
 }
@@ -263,7 +264,7 @@ template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
-    auto k = k_xinv<C, LPW, SPLIT>;
+    auto k = (n == C::L / 2) ? k_xinv<C, LPW, SPLIT, true> : k_xinv<C, LPW, SPLIT, false>;
     allow_lds(k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW, Wp, n);
 }
@@ -278,7 +279,7 @@ template <class C, bool SPLIT, int WPE> static void yfwd_t(const PrunedTuning& t
     constexpr int LINES = Tune<C>::LINES;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = k_yfwd<C, LINES, SPLIT, WPE>;
+    auto k = (m == C::L / 2) ? k_yfwd<C, LINES, SPLIT, WPE, true> : k_yfwd<C, LINES, SPLIT, WPE, false>;
     allow_lds(k, lds);
     int TG, TZ; ytile(tn, C::L, Lx / LINES, l, TG, TZ);
     hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a1, a2, tw, Lx, m, l, TG, TZ, p1, p2);
@@ -287,7 +288,7 @@ template <class C, bool SPLIT, int WPE> static void yinv_t(const PrunedTuning& t
     constexpr int LINES = Tune<C>::LINES;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = k_yinv<C, LINES, SPLIT, WPE>;
+    auto k = (m == C::L / 2) ? k_yinv<C, LINES, SPLIT, WPE, true> : k_yinv<C, LINES, SPLIT, WPE, false>;
     allow_lds(k, lds);
     int TG, TZ; ytile(tn, C::L, Lx / LINES, l, TG, TZ);
     hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l, TG, TZ, p1, p2);
@@ -300,7 +301,7 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     static_assert(XB % LINES == 0, "LINES must divide XB");
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = k_zfused<C, LINES, SPLIT, PREFETCH, WPE, false, ZE>;
+    auto k = (nin == C::L / 2) ? k_zfused<C, LINES, SPLIT, PREFETCH, WPE, false, ZE, true> : k_zfused<C, LINES, SPLIT, PREFETCH, WPE, false, ZE, false>;
     allow_lds(k, lds);
     if (LINES == XB) {
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / XB) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
@@ -321,7 +322,7 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     constexpr int LINES = 4;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true, ZE>;
+    auto k = (nin == C::L / 2) ? k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true, ZE, true> : k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true, ZE, false>;
     allow_lds(k, lds);
     const int64_t ntiles = (int64_t)(Lx / XB) * nouter;
     LSFC_REQUIRE(ntiles % 8 == 0, "half-tile z pass needs a multiple of 8 tiles");
