@@ -85,3 +85,19 @@ def test_distributed_plan_single_rank_production_path(lsfc, chunks, monkeypatch)
     u = np.zeros(M.N, complex)
     u, hist = lsfc.gmres_(u, M, rhs, restart=10, reltol=1e-8, log=True)
     assert hist.isconverged and np.linalg.norm(o.mul(Mo, u) - rhs) / np.linalg.norm(rhs) < 1e-7
+
+
+def test_simulated_ranks_grid_sizes_not_powers_of_two(lsfc):
+    # slab decomposition of a 24 x 20 x 18 grid (working grid 64 x 64 x 64): only l must divide by the rank count
+    n, m, l, k = 24, 20, 18, 7.0
+    h = 1.0 / n
+    rng = np.random.default_rng(12)
+    nu = rng.uniform(-0.3, 0.3, n * m * l)
+    b = o.random_vector(n * m * l)
+    x = -0.5 + h * np.arange(n)
+    M = lsfc.buildFastConvolution3D(x, x[:1].repeat(m), x[:1].repeat(l), None, None, None, h, k, nu)
+    ref = M * b
+    for nranks in (1, 2):
+        S = SimulatedRanks(n, m, l, h, k, nu, nranks)
+        assert rel_err(S.apply(b), ref) < 1e-13
+        S.close()
