@@ -20,6 +20,9 @@
 #include "common.hpp"
 #include "fft_configs.hpp"
 #include "pruned.hpp"
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace lsfc {
 using namespace fft;
@@ -240,9 +243,17 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// opt a kernel in to > 48 KiB of dynamic LDS, once per kernel and device (not on every launch)
 template <class K> static void allow_lds(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024)
-        LSFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes <= 48 * 1024) return;
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0; LSFC_HIP(hipGetDevice(&dev));
+    const std::pair<const void*, int> key(reinterpret_cast<const void*>(kernel), dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(key)) return;
+    LSFC_HIP(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.insert(key);
 }
 
 template <class C> struct Tune {
