@@ -26,8 +26,10 @@ void set_last_error(const char* fmt, ...);
     throw Error(code, buf);
 }
 
-#define LSFC_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
-    ::lsfc::fail(e_ == hipErrorOutOfMemory ? LSFC_ENOMEM : LSFC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+// (a failed call also leaves HIP's per-thread "last error" set: clear it so that a later hipGetLastError() check
+// does not report this failure a second time)
+#define LSFC_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
+    ::lsfc::fail(e_ == hipErrorOutOfMemory ? LSFC_ENOMEM : LSFC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 
 #define LSFC_REQUIRE(cond, ...) do { if (!(cond)) ::lsfc::fail(LSFC_EINVAL, __VA_ARGS__); } while (0)
 

@@ -47,7 +47,7 @@ static void phase2_yfwd(lsfc_plan* p, int c, hipStream_t st) {
 static void phase2_zfused(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
     const int Ly = p->pads[1], Lz = p->pads[2], l = p->dims[2];
-    pruned_zfused(Lz, p->tuning, p->A2.p + (int64_t)c * d->Wc * Ly * l, p->sym.p + (int64_t)c * d->Wc * p->sym_rows * p->sym_hz, p->tw[2].p, d->Wc, Ly,
+    pruned_zfused(Lz, p->tuning, p->A2.p + (int64_t)c * d->Wc * Ly * l, p->sym.p + (int64_t)c * d->Wc * p->sym_rows * p->sym_hz, p->tw[2].p, nullptr, d->Wc, Ly,
                   (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p,
                   p->zmirror.p, l, st);
 }

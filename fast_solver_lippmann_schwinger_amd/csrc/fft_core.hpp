@@ -155,6 +155,11 @@ template <int L_, int T_, int R0_, int R1_, int R2_ = 1, int R3_ = 1> struct Cfg
     static_assert(R3_ == 1 || R2_ > 1, "a 4th stage needs a 3rd");
     template <int S> static constexpr int LS() { return S == 0 ? L : (S == 1 ? L / R0 : (S == 2 ? L / (R0 * R1) : L / (R0 * R1 * R2))); }
     template <int S> static constexpr int R() { return S == 0 ? R0 : (S == 1 ? R1 : (S == 2 ? R2 : R3)); }
+    // full stage-twiddle table (optional, kept in LDS): stage S holds (R_S - 1) * M_S entries
+    // tw_full[TWOFF<S>() + (q-1)*M_S + r] = exp(-2 pi i * r*q / LS_S), q = 1..R_S-1, r < M_S = LS_S / R_S
+    template <int S> static constexpr int TWCNT() { return (LS<S>() / R<S>() > 1) ? (R<S>() - 1) * (LS<S>() / R<S>()) : 0; }
+    template <int S> static constexpr int TWOFF() { return S == 0 ? 0 : TWOFF<(S > 0 ? S - 1 : 0)>() + TWCNT<(S > 0 ? S - 1 : 0)>(); }
+    static constexpr int TWLEN = TWCNT<0>() + TWCNT<1>() + (NS >= 3 ? TWCNT<2>() : 0) + (NS >= 4 ? TWCNT<3>() : 0);
 };
 
 // In-place position touched by slot e of thread t in stage S.
@@ -216,7 +221,9 @@ __device__ __forceinline__ void exchange(cplx (&v)[C::E], int t, char* smem, int
 
 // One butterfly stage on the register slots.  PRUNE: 0 full; 1 forward with inputs
 // q >= R/2 zero; 2 inverse with only outputs q < R/2 wanted.
-template <class C, int S, int DIR, int PRUNE>
+// TWFULL: `tw` is the full stage-twiddle table (Cfg::TWOFF layout, normally staged in LDS): every power is read,
+// none is computed -- trades the product trees' fp64 work for LDS reads.
+template <class C, int S, int DIR, int PRUNE, bool TWFULL = false>
 __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __restrict__ tw) {
     constexpr int LS = C::template LS<S>(), R = C::template R<S>();
     constexpr int M = LS / R, NB = C::E / R;
@@ -228,9 +235,17 @@ __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __rest
         cplx w[R];
         if constexpr (M > 1) {
             const int r = (t + C::T * u) % M;
-            cplx w1 = tw[r * (C::L / LS)];
-            if constexpr (DIR < 0) w1 = cconj(w1);
-            twiddle_powers<R>(w1, w);
+            if constexpr (TWFULL) {
+#pragma unroll
+                for (int q = 1; q < R; ++q) {
+                    const cplx x = tw[C::template TWOFF<S>() + (q - 1) * M + r];
+                    w[q] = (DIR < 0) ? cconj(x) : x;
+                }
+            } else {
+                cplx w1 = tw[r * (C::L / LS)];
+                if constexpr (DIR < 0) w1 = cconj(w1);
+                twiddle_powers<R>(w1, w);
+            }
         }
         if constexpr (DIR < 0 && M > 1) {
 #pragma unroll
@@ -250,35 +265,35 @@ __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __rest
 
 #ifndef LSFC_FFT_HOST_EMULATION
 // natural (time) order in slots -> storage (digit-reversed frequency) order in slots
-template <class C, class LL, bool PRUNE_IN>
+template <class C, class LL, bool PRUNE_IN, bool TWFULL = false>
 __device__ __forceinline__ void fft_forward(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
-    stage<C, 0, +1, PRUNE_IN ? 1 : 0>(v, t, tw);
+    stage<C, 0, +1, PRUNE_IN ? 1 : 0, TWFULL>(v, t, tw);
     exchange<C, 0, 1, LL>(v, t, smem, off, xi);
-    stage<C, 1, +1, 0>(v, t, tw);
+    stage<C, 1, +1, 0, TWFULL>(v, t, tw);
     if constexpr (C::NS >= 3) {
         exchange<C, 1, 2, LL>(v, t, smem, off, xi);
-        stage<C, 2, +1, 0>(v, t, tw);
+        stage<C, 2, +1, 0, TWFULL>(v, t, tw);
     }
     if constexpr (C::NS >= 4) {
         exchange<C, 2, 3, LL>(v, t, smem, off, xi);
-        stage<C, 3, +1, 0>(v, t, tw);
+        stage<C, 3, +1, 0, TWFULL>(v, t, tw);
     }
 }
 
 // storage order in slots -> natural (time) order in slots, unnormalised
-template <class C, class LL, bool PRUNE_OUT>
+template <class C, class LL, bool PRUNE_OUT, bool TWFULL = false>
 __device__ __forceinline__ void fft_inverse(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
     if constexpr (C::NS >= 4) {
-        stage<C, 3, -1, 0>(v, t, tw);
+        stage<C, 3, -1, 0, TWFULL>(v, t, tw);
         exchange<C, 3, 2, LL>(v, t, smem, off, xi);
     }
     if constexpr (C::NS >= 3) {
-        stage<C, 2, -1, 0>(v, t, tw);
+        stage<C, 2, -1, 0, TWFULL>(v, t, tw);
         exchange<C, 2, 1, LL>(v, t, smem, off, xi);
     }
-    stage<C, 1, -1, 0>(v, t, tw);
+    stage<C, 1, -1, 0, TWFULL>(v, t, tw);
     exchange<C, 1, 0, LL>(v, t, smem, off, xi);
-    stage<C, 0, -1, PRUNE_OUT ? 2 : 0>(v, t, tw);
+    stage<C, 0, -1, PRUNE_OUT ? 2 : 0, TWFULL>(v, t, tw);
 }
 #endif // !LSFC_FFT_HOST_EMULATION
 
@@ -301,6 +316,22 @@ template <class C> inline void perm_table(int* freq_of_storage) {
             }
             freq_of_storage[t + C::T * e] = k;
         }
+}
+
+// Host mirror: fill the full stage-twiddle table of a factorisation from tw[j] = exp(-2 pi i j / L).
+template <class C, int S> inline void twfull_stage(cplx* out, const cplx* tw) {
+    constexpr int LS = C::template LS<S>(), R = C::template R<S>();
+    constexpr int M = LS / R;
+    if (M > 1)
+        for (int q = 1; q < R; ++q)
+            for (int r = 0; r < M; ++r)
+                out[C::template TWOFF<S>() + (q - 1) * M + r] = tw[((long long)r * q * (C::L / LS)) % C::L];
+}
+template <class C> inline void twfull_table(cplx* out, const cplx* tw) {
+    twfull_stage<C, 0>(out, tw);
+    twfull_stage<C, 1>(out, tw);
+    if (C::NS >= 3) twfull_stage<C, 2>(out, tw);
+    if (C::NS >= 4) twfull_stage<C, 3>(out, tw);
 }
 
 }} // namespace lsfc::fft

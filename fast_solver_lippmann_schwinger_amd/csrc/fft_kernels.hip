@@ -167,7 +167,9 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
 // (exactly the slots e < E/2 of every thread) plus the kz = L/2 entry at index L/2.  Each thread loads its E/2
 // values; the mirror values (kz -> L - kz) of its slots e >= E/2 are held by other threads of the same line and are
 // fetched through LDS (zm[s - L/2] = storage index of the partner).  Halves the symbol bytes of the pass again.
-template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF, bool ZE, bool EXACT>
+// TWL: the full stage-twiddle table (tw points to it) is staged in LDS behind the exchange buffer and read instead of
+// computing the power trees (-18 % fp64 instructions, +40 % LDS reads).
+template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF, bool ZE, bool EXACT, bool TWL>
 __global__ __launch_bounds__(C::T * LINES, WPE)
 void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
               int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
@@ -190,6 +192,12 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
     cplx* d = data + g * dGrp + outer * dOuter + xi;
     const cplx* s = sym + g * sGrp + srow * sOuter + xi;
     const int li = threadIdx.x % LINES;                 // line slot inside this workgroup's LDS
+    if constexpr (TWL) {
+        cplx* tl = reinterpret_cast<cplx*>(smem + (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes());
+        for (int i = threadIdx.x; i < C::TWLEN; i += C::T * LINES) tl[i] = tw[i];
+        __syncthreads();
+        tw = tl;
+    }
     cplx v[E];
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) v[e] = (EXACT || t + T * e < nin) ? d[dLine * (t + T * e)] : make_double2(0.0, 0.0);
@@ -205,7 +213,7 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
 #pragma unroll
             for (int e = 0; e < H; ++e) sv[e] = s[sLine * (t + T * e)];
         }
-        fft_forward<C, LL, true>(v, t, tw, smem, 0, li);
+        fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         if constexpr (!PREFETCH) {
 #pragma unroll
             for (int e = 0; e < H; ++e) sv[e] = s[sLine * (t + T * e)];
@@ -227,15 +235,15 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
         cplx sv[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) sv[e] = s[sLine * (t + T * e)];
-        fft_forward<C, LL, true>(v, t, tw, smem, 0, li);
+        fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = cmul(v[e], sv[e]);
     } else {
-        fft_forward<C, LL, true>(v, t, tw, smem, 0, li);
+        fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = cmul(v[e], s[sLine * (t + T * e)]);
     }
-    fft_inverse<C, LL, true>(v, t, tw, smem, 0, li);
+    fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) if (EXACT || t + T * e < nin) d[dLine * (t + T * e)] = v[e];
 }
@@ -304,15 +312,22 @@ template <class C, bool SPLIT, int WPE> static void yinv_t(const PrunedTuning& t
     int TG, TZ; ytile(tn, C::L, Lx / LINES, l, TG, TZ);
     hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l, TG, TZ, p1, p2);
 }
-template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                                                     int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
                                                     const int2* ytab, const int* zm, int nin, hipStream_t st) {
     // dTile/sTile are strides per XB-tile of x'; a workgroup covers LINES of the XB lines of a tile.
+    // twl != NULL: full stage-twiddle table, staged in LDS by the kernel.
     constexpr int LINES = Tune<C>::LINES;
     static_assert(XB % LINES == 0, "LINES must divide XB");
     using LL = LdsLayout<LINES, 3, SPLIT>;
-    const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = (nin == C::L / 2) ? k_zfused<C, LINES, SPLIT, PREFETCH, WPE, false, ZE, true> : k_zfused<C, LINES, SPLIT, PREFETCH, WPE, false, ZE, false>;
+    size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
+    auto k = (nin == C::L / 2) ? k_zfused<C, LINES, SPLIT, PREFETCH, WPE, false, ZE, true, false> : k_zfused<C, LINES, SPLIT, PREFETCH, WPE, false, ZE, false, false>;
+    if (twl && lds + (size_t)C::TWLEN * sizeof(cplx) > (size_t)160 * 1024) twl = nullptr;   // table does not fit beside the exchange buffer
+    if (twl) {
+        k = (nin == C::L / 2) ? k_zfused<C, LINES, SPLIT, PREFETCH, WPE, false, ZE, true, true> : k_zfused<C, LINES, SPLIT, PREFETCH, WPE, false, ZE, false, true>;
+        lds += (size_t)C::TWLEN * sizeof(cplx);
+        tw = twl;
+    }
     allow_lds(k, lds);
     if (LINES == XB) {
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / XB) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
@@ -333,7 +348,7 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     constexpr int LINES = 4;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
-    auto k = (nin == C::L / 2) ? k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true, ZE, true> : k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true, ZE, false>;
+    auto k = (nin == C::L / 2) ? k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true, ZE, true, false> : k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true, ZE, false, false>;
     allow_lds(k, lds);
     const int64_t ntiles = (int64_t)(Lx / XB) * nouter;
     LSFC_REQUIRE(ntiles % 8 == 0, "half-tile z pass needs a multiple of 8 tiles");
@@ -374,6 +389,7 @@ PrunedTuning pruned_default_tuning() {
     if (const char* v = getenv("LSFC_PAD1")) t.pad1 = atoi(v);
     if (const char* v = getenv("LSFC_PAD2")) t.pad2 = atoi(v);
     if (const char* v = getenv("LSFC_Z_HALF")) t.z_half = atoi(v);
+    if (const char* v = getenv("LSFC_TW_LDS")) t.tw_lds = atoi(v);
     if (const char* v = getenv("LSFC_SYM_PREFETCH")) t.sym_prefetch = atoi(v);
     if (const char* v = getenv("LSFC_YTILE_G")) t.ytile_g = atoi(v);
     if (const char* v = getenv("LSFC_YTILE_Z")) t.ytile_z = atoi(v);
@@ -404,11 +420,20 @@ void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const 
     else            { LSFC_DISPATCH_L(L, (yinv_t<C, false, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+int pruned_twfull_len(int L) {
+    int len = 0;
+    LSFC_DISPATCH_L(L, len = C::TWLEN);
+    return len;
+}
+void pruned_twfull(int L, const cplx* tw, cplx* out) {
+    LSFC_DISPATCH_L(L, twfull_table<C>(out, tw));
+}
+
+void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, const int2* ytab,
                    const int* zm, int nin, hipStream_t st) {
-#define LSFC_ZF(SP, PF) do { if (zm) { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); } \
-                             else    { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); } } while (0)
+#define LSFC_ZF(SP, PF) do { if (zm) { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); } \
+                             else    { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, false>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); } } while (0)
     // auto (-1): half-tile, split exchanges, symbol prefetch -- 6.95 -> 6.6 ms at 512^3 (profiles/r01_experiment_half_tile.log)
     // with the z-even half symbol the full-tile form wins (6.05 ms, profiles/r01_experiment_even_z.log)
     const int zh = tn.z_half >= 0 ? tn.z_half : (zm ? 0 : 2);

@@ -104,6 +104,10 @@ static void make_twiddles(lsfc_plan* p, int axis, int L) {
     }
     p->tw[axis].alloc((size_t)L);
     LSFC_HIP(hipMemcpy(p->tw[axis].p, tw.data(), (size_t)L * sizeof(cplx), hipMemcpyHostToDevice));
+    std::vector<cplx> full((size_t)pruned_twfull_len(L) + 1);
+    pruned_twfull(L, tw.data(), full.data());
+    p->twl[axis].alloc(full.size());
+    LSFC_HIP(hipMemcpy(p->twl[axis].p, full.data(), full.size() * sizeof(cplx), hipMemcpyHostToDevice));
 }
 
 static int next_pow2(int v) { int p2 = 1; while (p2 < v) p2 <<= 1; return p2; }
@@ -301,12 +305,12 @@ void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
         if (p->ndim == 3) {
             const int p1 = p->pitch1, p2 = p->pitch2;
             pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, p1, p2, st);
-            pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
+            pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, p->twl[2].p, Lx, Ly,
                           (int64_t)p2 * Ly, (int64_t)p2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p,
                           p->zmirror.p, l, st);
             pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p1, p2, st);
         } else {
-            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, m, st);
+            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, m, st);
         }
         pruned_xinv(Lx, p->tuning, p->A1.p, x, y, alpha, beta, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st);
     } else {
@@ -579,6 +583,7 @@ int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value) {
         else if (k == "split_s") plan->tuning.split_s = value != 0;
         else if (k == "split_z") plan->tuning.split_z = value;
         else if (k == "z_half") plan->tuning.z_half = value;
+        else if (k == "tw_lds") plan->tuning.tw_lds = value;
         else if (k == "sym_prefetch") plan->tuning.sym_prefetch = value;
         else if (k == "ytile_g") plan->tuning.ytile_g = value;
         else if (k == "ytile_z") plan->tuning.ytile_z = value;
@@ -627,12 +632,12 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
             stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, [=] { pruned_xfwd(Lx, p->tuning, x, p->nu.p, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st); }});
             if (p->ndim == 3) {
                 stages.push_back({"yfwd", (2 + 4) * N * C, [=] { pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, p->pitch1, p->pitch2, st); }});
-                stages.push_back({"zfused", (4 + 8 + 4) * N * C, [=] { pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, Lx, Ly,
+                stages.push_back({"zfused", (4 + 8 + 4) * N * C, [=] { pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, p->twl[2].p, Lx, Ly,
                                   (int64_t)p->pitch2 * Ly, (int64_t)p->pitch2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8,
                                   p->ytab.p, p->zmirror.p, l, st); }});
                 stages.push_back({"yinv", (4 + 2) * N * C, [=] { pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p->pitch1, p->pitch2, st); }});
             } else {
-                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, m, st); }});
+                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, m, st); }});
             }
             stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st); }});
         } else {

@@ -81,6 +81,7 @@ struct lsfc_plan {
     // pruned pipeline
     lsfc::PrunedTuning tuning;
     lsfc::DevBuf<lsfc::cplx> tw[3];
+    lsfc::DevBuf<lsfc::cplx> twl[3];     // full stage-twiddle tables (pruned_twfull)
     lsfc::DevBuf<lsfc::cplx> A1, A2;
     // y-even symbol: only rows with ky <= Ly/2 are stored (sym_rows of them); ytab[o] = (data row, symbol row) in block order
     int sym_rows = 0;

@@ -10,6 +10,8 @@ struct PrunedTuning {
     int split_z = -1;      // fused z pass: 1 split, 0 whole complex, -1 auto (by line length)
     int sym_prefetch = -1; // z pass: load the symbol before the forward transform; -1 auto
     int pad1 = -1, pad2 = -1;        // row padding (elements, multiples of 8) of the A1 rows / A2 tile rows, read at plan creation
+    int tw_lds = 1;                 // fused pass (full-tile form): stage twiddles from an LDS-resident table instead of product
+                                    // trees (-2..3 % on the pass, exact twiddles; profiles/r01_experiment_lds_twiddle_table.log)
     int z_half = -1;                // L = 1024 z pass: half-tile 4-wave workgroups (0 off, 1: full+prefetch, 2: split+prefetch, 3: split 3 WG/CU, 4: full; -1 auto)
     int ytile_g = 0, ytile_z = 0;   // y passes: block-order tile (x'-groups x z planes); 0 = auto
 };
@@ -29,7 +31,10 @@ void pruned_xinv(int L, const PrunedTuning&, const cplx* in, const cplx* xorig, 
 // p1: row pitch of A1 (>= Lx), p2: pitch of one storage-y row of an A2 tile (>= 8*l); both multiples of 8 elements
 void pruned_yfwd(int L, const PrunedTuning&, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);
 void pruned_yinv(int L, const PrunedTuning&, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);
-void pruned_zfused(int L, const PrunedTuning&, cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+// full stage-twiddle table of the factorisation used for length L (host side; tw[j] = exp(-2 pi i j / L))
+int pruned_twfull_len(int L);
+void pruned_twfull(int L, const cplx* tw, cplx* out);
+void pruned_zfused(int L, const PrunedTuning&, cplx* data, const cplx* sym, const cplx* tw, const cplx* twl /* full table or NULL */, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
                    const int2* ytab /* block order -> (data row, symbol row); NULL: identity */,
                    const int* zm /* z-even symbol: partner storage index of every upper-half slot; NULL: full symbol lines */,

@@ -42,11 +42,15 @@ static void emu_exchange(std::vector<std::vector<cplx>>& regs, std::vector<char>
     }
 }
 
+static bool g_twfull = false;        // second sweep: stage twiddles read from the full table instead of computed
 template <class C, int S, int DIR, int PRUNE>
 static void emu_stage(std::vector<std::vector<cplx>>& regs, int nlines, const cplx* tw) {
+    std::vector<cplx> full((size_t)C::TWLEN + 1);
+    twfull_table<C>(full.data(), tw);
     for (int line = 0; line < nlines; ++line) for (int t = 0; t < C::T; ++t) {
         cplx (&v)[C::E] = *reinterpret_cast<cplx(*)[C::E]>(regs[line * C::T + t].data());
-        stage<C, S, DIR, PRUNE>(v, t, tw);
+        if (g_twfull) stage<C, S, DIR, PRUNE, true>(v, t, full.data());
+        else stage<C, S, DIR, PRUNE>(v, t, tw);
     }
 }
 
@@ -105,7 +109,11 @@ int main() {
     worst = fmax(worst, run_cfg<CFG, LdsLayout<1, 3, false>>(#CFG " contig full", false)); \
     worst = fmax(worst, run_cfg<CFG, LdsLayout<8, 3, true>>(#CFG " strided split", true)); \
     worst = fmax(worst, run_cfg<CFG, LdsLayout<8, 3, false>>(#CFG " strided full", true)); } while (0)
+    for (int pass = 0; pass < 2; ++pass) {
+    g_twfull = pass == 1;
+    printf("---- stage twiddles: %s\n", g_twfull ? "full table" : "product tree");
     RUN(Cfg32); RUN(Cfg64); RUN(Cfg128); RUN(Cfg256); RUN(Cfg512); RUN(Cfg1024); RUN(Cfg2048); RUN(Cfg1024S);
+    }
     printf("worst=%.3e\n", worst);
     return worst < 1e-13 ? 0 : 1;
 }
