@@ -41,21 +41,21 @@ static void phase1(lsfc_plan* p, const cplx* x, bool use_nu, hipStream_t st) {
 static void phase2_yfwd(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
     const int m = p->dims[1], l = p->dims[2];
-    pruned_yfwd(p->pads[1], p->tuning, d->R1.p + (int64_t)c * d->Wc * m * l, p->A2.p + (int64_t)c * d->Wc * p->pads[1] * l,
-                p->tw[1].p, d->Wc, m, l, d->Wc, 8 * l, st);
+    pruned_yfwd(p->pads[1], p->tuning, d->R1.p + (int64_t)c * d->Wc * m * l, p->A2.p + (int64_t)c * (d->Wc / 8) * p->pads[1] * p->pitch2,
+                p->tw[1].p, d->Wc, m, l, d->Wc, p->pitch2, st);
 }
 static void phase2_zfused(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
     const int Ly = p->pads[1], Lz = p->pads[2], l = p->dims[2];
-    pruned_zfused(Lz, p->tuning, p->A2.p + (int64_t)c * d->Wc * Ly * l, p->sym.p + (int64_t)c * d->Wc * p->sym_rows * p->sym_hz, p->tw[2].p, nullptr, d->Wc, Ly,
-                  (int64_t)8 * l * Ly, (int64_t)8 * l, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p,
+    pruned_zfused(Lz, p->tuning, p->A2.p + (int64_t)c * (d->Wc / 8) * Ly * p->pitch2, p->sym.p + (int64_t)c * d->Wc * p->sym_rows * p->sym_hz, p->tw[2].p, p->twl[2].p, d->Wc, Ly,
+                  (int64_t)p->pitch2 * Ly, (int64_t)p->pitch2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p,
                   p->zmirror.p, l, st);
 }
 static void phase2_yinv(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
     const int m = p->dims[1], l = p->dims[2];
-    pruned_yinv(p->pads[1], p->tuning, p->A2.p + (int64_t)c * d->Wc * p->pads[1] * l, d->R1.p + (int64_t)c * d->Wc * m * l,
-                p->tw[1].p, d->Wc, m, l, d->Wc, 8 * l, st);
+    pruned_yinv(p->pads[1], p->tuning, p->A2.p + (int64_t)c * (d->Wc / 8) * p->pads[1] * p->pitch2, d->R1.p + (int64_t)c * d->Wc * m * l,
+                p->tw[1].p, d->Wc, m, l, d->Wc, p->pitch2, st);
 }
 static void phase2(lsfc_plan* p, int c, hipStream_t st) { phase2_yfwd(p, c, st); phase2_zfused(p, c, st); phase2_yinv(p, c, st); }
 static void phase3(lsfc_plan* p, const cplx* x, cplx* y, double alpha, double beta, hipStream_t st) {
@@ -141,25 +141,16 @@ void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y, std::function<voi
     const int K = d->K;
     // un-overlapped, stage by stage, all on the plan's stream (the production path overlaps the exchanges)
     add("xfwd", N * (C + 8) + 2 * N * C, [=] { phase1(p, x, true, st); });
-    add("alltoall_in", 2 * N * C, [=] { for (int c = 0; c < K; ++c) exchange(p, c, false, st); });
+    const bool sim = d->sim;                                    // simulated rank: compute stages only (per-rank kernel times at P ranks)
+    if (!sim) add("alltoall_in", 2 * N * C, [=] { for (int c = 0; c < K; ++c) exchange(p, c, false, st); });
     add("yfwd", 6 * N * C, [=] { for (int c = 0; c < K; ++c) phase2_yfwd(p, c, st); });
     add("zfused", 16 * N * C, [=] { for (int c = 0; c < K; ++c) phase2_zfused(p, c, st); });
     add("yinv", 6 * N * C, [=] { for (int c = 0; c < K; ++c) phase2_yinv(p, c, st); });
-    add("alltoall_back", 2 * N * C, [=] { for (int c = 0; c < K; ++c) exchange(p, c, true, st); });
+    if (!sim) add("alltoall_back", 2 * N * C, [=] { for (int c = 0; c < K; ++c) exchange(p, c, true, st); });
     add("xinv", 4 * N * C, [=] { phase3(p, x, y, 1.0, om2, st); });
 }
 
 // ---------------------------------------------------------------------------
-static void make_twiddles_dist(lsfc_plan* p, int axis, int L) {
-    std::vector<cplx> tw((size_t)L);
-    for (int j = 0; j < L; ++j) {
-        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)L;
-        tw[j] = make_double2((double)cosl(a), (double)sinl(a));
-    }
-    p->tw[axis].alloc((size_t)L);
-    LSFC_HIP(hipMemcpy(p->tw[axis].p, tw.data(), (size_t)L * sizeof(cplx), hipMemcpyHostToDevice));
-}
-
 static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega, const double* nu_local,
                              unsigned flags, int device, int rank, int nranks, const unsigned char* id, bool sim) {
     LSFC_REQUIRE(out, "NULL argument"); *out = nullptr;
@@ -221,7 +212,7 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
         pruned_perm(p->pads[a], perm[a].data());
         dperm[a].alloc(perm[a].size());
         LSFC_HIP(hipMemcpy(dperm[a].p, perm[a].data(), perm[a].size() * sizeof(int), hipMemcpyHostToDevice));
-        make_twiddles_dist(p.get(), a, p->pads[a]);
+        plan_make_twiddles(p.get(), a, p->pads[a]);
     }
     const int ntiles = d->W / 8;
     const double scale = 1.0 / ((double)p->pads[0] * p->pads[1] * p->pads[2]);
@@ -233,7 +224,14 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     G2.release();
     d->S1.alloc((size_t)p->pads[0] * m * lz);
     d->R1.alloc((size_t)d->W * m * l);
-    p->A2.alloc((size_t)d->W * p->pads[1] * l);
+    // A2 rows are padded like the single-GPU plan's (the message buffers S1 / R1 stay dense: their blocks are the messages)
+    const int pad2 = p->tuning.pad2 >= 0 ? p->tuning.pad2 : (p->pads[1] >= 1024 ? 72 : 0);
+    p->pitch1 = d->Wc;
+    p->pitch2 = 8 * (int)l + pad2 / 8 * 8;
+    p->A2.alloc((size_t)(d->W / 8) * p->pads[1] * p->pitch2);
+    LSFC_HIP(hipMemset(d->S1.p, 0, d->S1.bytes()));
+    LSFC_HIP(hipMemset(d->R1.p, 0, d->R1.bytes()));
+    LSFC_HIP(hipMemset(p->A2.p, 0, p->A2.bytes()));
     p->pipeline = lsfc_plan::PRUNED;
     *out = p.release();
 }

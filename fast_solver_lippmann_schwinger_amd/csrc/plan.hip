@@ -96,7 +96,7 @@ void plan_common_init(lsfc_plan* p, int ndim, int64_t n, int64_t m, int64_t l, c
     p->tuning = pruned_default_tuning();
 }
 
-static void make_twiddles(lsfc_plan* p, int axis, int L) {
+void plan_make_twiddles(lsfc_plan* p, int axis, int L) {
     std::vector<cplx> tw((size_t)L);
     for (int j = 0; j < L; ++j) {
         const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)L;
@@ -226,7 +226,7 @@ void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
             pruned_perm(p->pads[d], perm[d].data());
             dperm[d].alloc(perm[d].size());
             LSFC_HIP(hipMemcpy(dperm[d].p, perm[d].data(), perm[d].size() * sizeof(int), hipMemcpyHostToDevice));
-            make_twiddles(p, d, p->pads[d]);
+            plan_make_twiddles(p, d, p->pads[d]);
         }
         if (p->ndim == 3) {
             DevBuf<int> pyrow;
@@ -613,7 +613,6 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
         LSFC_REQUIRE(plan && x_dev && y_dev && names && ms && bytes && nstages && reps >= 1, "bad argument");
         LSFC_HIP(hipSetDevice(plan->device));
         lsfc_plan* p = plan;
-        LSFC_REQUIRE(!p->dist || !p->dist->sim, "profile_apply: not available for simulated ranks");
         const cplx* x = (const cplx*)x_dev; cplx* y = (cplx*)y_dev;
         hipStream_t st = p->stream;
         const double N = (double)p->N, C = 16.0;

@@ -142,6 +142,8 @@ void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y,
 
 // symbol rows / block order of the z pass for a (possibly) y-even symbol: fills p->sym_rows, p->ytab, returns the
 // device table of the y frequency of every stored row (plan.hip)
+// roots of unity of one axis: the per-line table tw[] and the full stage-twiddle table twl[] (pruned_twfull)
+void plan_make_twiddles(lsfc_plan* p, int axis, int L);
 void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>& perm_y, const std::vector<int>& perm_z, DevBuf<int>& pyrow);
 
 // GMRES (gmres.hip)
