@@ -23,7 +23,7 @@ namespace lsfc {
 
 DistState::~DistState() {
     for (auto& v : { &ev_in, &ev_done, &ev_back }) for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
-    if (ev_p1) (void)hipEventDestroy(ev_p1);
+    for (hipEvent_t e : { ev_p1, ev_p1a, ev_backa }) if (e) (void)hipEventDestroy(e);
     if (cs1) (void)hipStreamDestroy(cs1);
     if (cs2) (void)hipStreamDestroy(cs2);
     if (comm2) (void)ncclCommDestroy((ncclComm_t)comm2);
@@ -33,10 +33,13 @@ DistState::~DistState() {
 // block of one (rank, chunk) pair in S1 / R1: [Wc][m][lz]
 static int64_t block_elems(const lsfc_plan* p) { return (int64_t)p->dist->Wc * p->dims[1] * p->dist->lz; }
 
-static void phase1(lsfc_plan* p, const cplx* x, bool use_nu, hipStream_t st) {
+// part = -1: all own planes; part = 0 / 1: the lower / upper half of them (the z halves of every S1 block)
+static void phase1(lsfc_plan* p, const cplx* x, bool use_nu, hipStream_t st, int part = -1) {
     const DistState* d = p->dist.get();
+    const int64_t all = (int64_t)p->dims[1] * d->lz, nl = part < 0 ? all : all / 2, l0 = part == 1 ? all / 2 : 0;
     // chunk width Wc: storage index s of a line lands in block s / Wc = dest_rank * K + chunk
-    pruned_xfwd(p->pads[0], p->tuning, x, use_nu ? p->nu.p : nullptr, d->S1.p, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, d->Wc, p->dims[0], st);
+    pruned_xfwd(p->pads[0], p->tuning, x + l0 * p->dims[0], use_nu ? p->nu.p + l0 * p->dims[0] : nullptr, d->S1.p + l0 * d->Wc, p->tw[0].p,
+                nl, d->Wc, d->Wc, p->dims[0], st, all * d->Wc);
 }
 static void phase2_yfwd(lsfc_plan* p, int c, hipStream_t st) {
     const DistState* d = p->dist.get();
@@ -58,19 +61,22 @@ static void phase2_yinv(lsfc_plan* p, int c, hipStream_t st) {
                 p->tw[1].p, d->Wc, m, l, d->Wc, p->pitch2, st);
 }
 static void phase2(lsfc_plan* p, int c, hipStream_t st) { phase2_yfwd(p, c, st); phase2_zfused(p, c, st); phase2_yinv(p, c, st); }
-static void phase3(lsfc_plan* p, const cplx* x, cplx* y, double alpha, double beta, hipStream_t st) {
+static void phase3(lsfc_plan* p, const cplx* x, cplx* y, double alpha, double beta, hipStream_t st, int part = -1) {
     const DistState* d = p->dist.get();
-    pruned_xinv(p->pads[0], p->tuning, d->S1.p, x, y, alpha, beta, p->tw[0].p, (int64_t)p->dims[1] * d->lz, d->Wc, d->Wc, p->dims[0], st);
+    const int64_t all = (int64_t)p->dims[1] * d->lz, nl = part < 0 ? all : all / 2, l0 = part == 1 ? all / 2 : 0;
+    pruned_xinv(p->pads[0], p->tuning, d->S1.p + l0 * d->Wc, x + l0 * p->dims[0], y + l0 * p->dims[0], alpha, beta, p->tw[0].p,
+                nl, d->Wc, d->Wc, p->dims[0], st, all * d->Wc);
 }
 
 // Exchange of chunk c.  way in : S1 block (q*K + c)  -> rank q, lands in R1 chunk c at slot <source rank>
 //                       way back: R1 chunk c, slot q  -> rank q, lands in S1 block (<source rank>*K + c)
-static void exchange(lsfc_plan* p, int c, bool back, hipStream_t st) {
+// part = -1: whole blocks; 0 / 1: their lower / upper z halves (blocks are [z][m][Wc], z slowest: halves are contiguous)
+static void exchange(lsfc_plan* p, int c, bool back, hipStream_t st, int part = -1) {
     DistState* d = p->dist.get();
-    const int64_t B = block_elems(p);
+    const int64_t Bfull = block_elems(p), B = part < 0 ? Bfull : Bfull / 2, off = part == 1 ? Bfull / 2 : 0;
     const int K = d->K, P = d->nranks;
-    auto s1 = [&](int r) { return d->S1.p + ((int64_t)r * K + c) * B; };
-    auto r1 = [&](int r) { return d->R1.p + ((int64_t)c * P + r) * B; };
+    auto s1 = [&](int r) { return d->S1.p + ((int64_t)r * K + c) * Bfull + off; };
+    auto r1 = [&](int r) { return d->R1.p + ((int64_t)c * P + r) * Bfull + off; };
     const cplx* self_src = back ? r1(d->rank) : s1(d->rank);
     cplx* self_dst = back ? s1(d->rank) : r1(d->rank);
     ncclComm_t comm = (ncclComm_t)(back ? d->comm2 : d->comm);
@@ -98,34 +104,64 @@ void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
     DistState* d = p->dist.get();
     LSFC_REQUIRE(!d->sim, "simulated ranks are driven through lsfc_dist_sim_apply");
     hipStream_t st = p->stream;
-    phase1(p, x, use_nu, st);
     // LSFC_DIST_OVERLAP=0: no overlap -- every exchange on the compute stream, chunk after chunk (debugging aid)
     static const bool no_overlap = getenv("LSFC_DIST_OVERLAP") && getenv("LSFC_DIST_OVERLAP")[0] == '0';
     if ((d->nranks == 1 && !d->force_overlap) || no_overlap) {
+        phase1(p, x, use_nu, st);
         for (int c = 0; c < d->K; ++c) { exchange(p, c, false, st); phase2(p, c, st); exchange(p, c, true, st); }
         phase3(p, x, y, alpha, beta, st);
         return;
     }
     // software pipeline over the K chunks of the owned x' range: the all-to-all of chunk c+1 (stream cs1) and the
-    // all-to-all back of chunk c-1 (stream cs2, second communicator) run while chunk c is transformed (stream st)
+    // all-to-all back of chunk c-1 (stream cs2, second communicator) run while chunk c is transformed (stream st).
+    // The two ends of the pipeline are split once more over the z halves of the own slab, so that the first exchange
+    // starts after half of the x pass and the second half of the last exchange back hides half of the inverse x pass.
+    const bool no_edges = getenv("LSFC_DIST_SPLIT_EDGES") && getenv("LSFC_DIST_SPLIT_EDGES")[0] == '0';
+    const bool edges = !no_edges && d->lz % 2 == 0;
+    const int K = d->K;
+    if (edges) {
+        phase1(p, x, use_nu, st, 0);
+        LSFC_HIP(hipEventRecord(d->ev_p1a, st));
+        phase1(p, x, use_nu, st, 1);
+    } else {
+        phase1(p, x, use_nu, st);
+    }
     LSFC_HIP(hipEventRecord(d->ev_p1, st));
+    if (edges) {
+        LSFC_HIP(hipStreamWaitEvent(d->cs1, d->ev_p1a, 0));
+        exchange(p, 0, false, d->cs1, 0);
+    }
     LSFC_HIP(hipStreamWaitEvent(d->cs1, d->ev_p1, 0));
     LSFC_HIP(hipStreamWaitEvent(d->cs2, d->ev_p1, 0));      // also orders cs2 after the previous apply's xinv reads of S1
-    for (int c = 0; c < d->K; ++c) {
-        exchange(p, c, false, d->cs1);
+    for (int c = 0; c < K; ++c) {
+        if (edges && c == 0) exchange(p, 0, false, d->cs1, 1); else exchange(p, c, false, d->cs1);
         LSFC_HIP(hipEventRecord(d->ev_in[c], d->cs1));
     }
-    for (int c = 0; c < d->K; ++c) {
+    for (int c = 0; c < K; ++c) {
         LSFC_HIP(hipStreamWaitEvent(st, d->ev_in[c], 0));
         phase2(p, c, st);
         LSFC_HIP(hipEventRecord(d->ev_done[c], st));
         LSFC_HIP(hipStreamWaitEvent(d->cs2, d->ev_done[c], 0));
         // (the S1 blocks this receive overwrites belong to chunk c, whose way-in sends finished before ev_in[c])
-        exchange(p, c, true, d->cs2);
+        if (edges && c == K - 1) {
+            exchange(p, c, true, d->cs2, 0);
+            LSFC_HIP(hipEventRecord(d->ev_backa, d->cs2));
+            exchange(p, c, true, d->cs2, 1);
+        } else {
+            exchange(p, c, true, d->cs2);
+        }
         LSFC_HIP(hipEventRecord(d->ev_back[c], d->cs2));
     }
-    for (int c = 0; c < d->K; ++c) LSFC_HIP(hipStreamWaitEvent(st, d->ev_back[c], 0));
-    phase3(p, x, y, alpha, beta, st);
+    if (edges) {
+        // cs2 runs its exchanges in order: ev_backa implies every earlier chunk is back
+        LSFC_HIP(hipStreamWaitEvent(st, d->ev_backa, 0));
+        phase3(p, x, y, alpha, beta, st, 0);
+        LSFC_HIP(hipStreamWaitEvent(st, d->ev_back[K - 1], 0));
+        phase3(p, x, y, alpha, beta, st, 1);
+    } else {
+        for (int c = 0; c < K; ++c) LSFC_HIP(hipStreamWaitEvent(st, d->ev_back[c], 0));
+        phase3(p, x, y, alpha, beta, st);
+    }
 }
 
 void dist_allreduce_sum(lsfc_plan* p, cplx* dev, int count) {
@@ -194,7 +230,7 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     if (!sim && (nranks > 1 || d->force_overlap)) {
         LSFC_HIP(hipStreamCreateWithFlags(&d->cs1, hipStreamNonBlocking));
         LSFC_HIP(hipStreamCreateWithFlags(&d->cs2, hipStreamNonBlocking));
-        LSFC_HIP(hipEventCreateWithFlags(&d->ev_p1, hipEventDisableTiming));
+        for (hipEvent_t* e : { &d->ev_p1, &d->ev_p1a, &d->ev_backa }) LSFC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         d->ev_in.resize((size_t)K); d->ev_done.resize((size_t)K); d->ev_back.resize((size_t)K);
         for (int c = 0; c < K; ++c) {
             LSFC_HIP(hipEventCreateWithFlags(&d->ev_in[c], hipEventDisableTiming));

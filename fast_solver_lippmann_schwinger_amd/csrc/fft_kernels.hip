@@ -33,7 +33,7 @@ static constexpr int XB = 8;           // x' lines per strided workgroup: 8 * 16
 template <class C, int LPW, bool SPLIT, bool EXACT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __restrict__ out,
-            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp, int n) {
+            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp, int n, int64_t bstride) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -60,7 +60,7 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int s = t + T * e;
-            out[(int64_t)(s >> logW) * ((int64_t)Wp * nlines) + line * Wp + (s & (W - 1))] = v[e];
+            out[(int64_t)(s >> logW) * bstride + line * Wp + (s & (W - 1))] = v[e];
         }
     }
 }
@@ -68,7 +68,7 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
 template <class C, int LPW, bool SPLIT, bool EXACT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alpha, double beta,
-            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp, int n) {
+            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp, int n, int64_t bstride) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -81,7 +81,7 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int s = t + T * e;
-        v[e] = in[(int64_t)(s >> logW) * ((int64_t)Wp * nlines) + lc * Wp + (s & (W - 1))];
+        v[e] = in[(int64_t)(s >> logW) * bstride + lc * Wp + (s & (W - 1))];
     }
     fft_inverse<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
     if (valid) {
@@ -271,21 +271,21 @@ template <class C> struct Tune {
     static constexpr int LINES = (C::T * XB <= 512 || (C::E <= 8 && C::T * XB <= 1024)) ? XB : 512 / C::T;
 };
 
-template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int logW, int Wp, int n, hipStream_t st) {
+template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int logW, int Wp, int n, int64_t bstride, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = (n == C::L / 2) ? k_xfwd<C, LPW, SPLIT, true> : k_xfwd<C, LPW, SPLIT, false>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW, Wp, n);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW, Wp, n, bstride);
 }
-template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int logW, int Wp, int n, hipStream_t st) {
+template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int logW, int Wp, int n, int64_t bstride, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = (n == C::L / 2) ? k_xinv<C, LPW, SPLIT, true> : k_xinv<C, LPW, SPLIT, false>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW, Wp, n);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW, Wp, n, bstride);
 }
 static void ytile(const PrunedTuning& tn, int L, int ngrp, int l, int& TG, int& TZ) {
     // auto (0): all groups x 1 plane, except at L >= 1024 where 32 groups x 8 planes keeps the 128-B chunks that the
@@ -398,16 +398,18 @@ PrunedTuning pruned_default_tuning() {
 
 static int log2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; LSFC_REQUIRE((1 << l) == v, "chunk width %d is not a power of two", v); return l; }
 
-void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st) {
+void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
     const int logW = log2_exact(W);
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, logW, Wp, n, st))); }
-    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, logW, Wp, n, st))); }
+    if (bstride <= 0) bstride = (int64_t)Wp * nlines;       // dense chunks: [chunk][line][Wp]
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, logW, Wp, n, bstride, st))); }
+    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, logW, Wp, n, bstride, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st) {
+void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
     const int logW = log2_exact(W);
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, n, st))); }
-    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, n, st))); }
+    if (bstride <= 0) bstride = (int64_t)Wp * nlines;       // dense chunks: [chunk][line][Wp]
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, n, bstride, st))); }
+    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, n, bstride, st))); }
     LSFC_HIP(hipGetLastError());
 }
 void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {

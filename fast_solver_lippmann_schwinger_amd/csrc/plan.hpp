@@ -56,7 +56,7 @@ struct DistState {
     DevBuf<cplx> R1;         // [K][Wc][m][l]: per chunk the natural layout on its x' range (received blocks concatenated)
     hipStream_t cs1 = nullptr, cs2 = nullptr;      // communication streams (in / back)
     std::vector<hipEvent_t> ev_in, ev_done, ev_back;
-    hipEvent_t ev_p1 = nullptr;
+    hipEvent_t ev_p1 = nullptr, ev_p1a = nullptr, ev_backa = nullptr;   // x pass done / its first z half done / first z half of the last chunk back
     ~DistState();
 };
 

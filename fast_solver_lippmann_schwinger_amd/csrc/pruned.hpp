@@ -25,9 +25,10 @@ bool pruned_length_supported(int64_t L);
 void pruned_perm(int L, int* freq_of_storage);
 PrunedTuning pruned_default_tuning();
 
-void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t);
+void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t,
+                 int64_t bstride = 0);     // bstride: distance between chunks of the storage axis (0: dense, Wp * nlines)
 void pruned_xinv(int L, const PrunedTuning&, const cplx* in, const cplx* xorig, cplx* y, double alpha, double beta,
-                 const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t);
+                 const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t, int64_t bstride = 0);
 // p1: row pitch of A1 (>= Lx), p2: pitch of one storage-y row of an A2 tile (>= 8*l); both multiples of 8 elements
 void pruned_yfwd(int L, const PrunedTuning&, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);
 void pruned_yinv(int L, const PrunedTuning&, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);

@@ -39,7 +39,8 @@ def test_simulated_ranks_noncubic_equals_single_gpu(lsfc):
         S.close()
 
 
-def test_three_stream_pipeline_event_logic_single_rank(lsfc, monkeypatch):
+@pytest.mark.parametrize("split_edges", ["1", "0"])
+def test_three_stream_pipeline_event_logic_single_rank(lsfc, monkeypatch, split_edges):
     # the overlapped production pipeline (compute stream + two exchange streams + events), forced on with one rank:
     # repeated applies on device-resident vectors must stay bitwise identical to the sequential path
     import torch
@@ -53,6 +54,7 @@ def test_three_stream_pipeline_event_logic_single_rank(lsfc, monkeypatch):
     Mseq = build_distributed_3d(n, h, 12.0, nu, 0, 1, 0)
     ref = Mseq * b
     monkeypatch.setenv("LSFC_DIST_FORCE_OVERLAP", "1")
+    monkeypatch.setenv("LSFC_DIST_SPLIT_EDGES", split_edges)   # z-half split of the first exchange in / last exchange back
     Mov = build_distributed_3d(n, h, 12.0, nu, 0, 1, 0)
     xb = torch.from_numpy(b).cuda()
     yb = torch.empty_like(xb)
