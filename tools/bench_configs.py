@@ -2,7 +2,7 @@
   configs[1]  2D n=1024 fp64 apply on one MI355X
   configs[2]  3D n=256 fp64, full GMRES(30) solve to 1e-6 (rhs from a plane wave, examples/example3D.jl:71-78)
   configs[4]  3D n=512 at omega = 64 pi (lattice points on |s| = k, patched symbol): apply rate + finite check
-usage: python tools/bench_configs.py [2d] [gmres] [hf]"""
+usage: python tools/bench_configs.py [2d] [gmres] [hf] [hfgmres] [gmres512] [host]"""
 import json
 import os
 import sys
@@ -77,6 +77,39 @@ def bench_hf(n=512):
     return {"config": f"3D n={n} omega=64pi patched symbol", "ms_per_apply": ms, "finite": bool(torch.isfinite(torch.view_as_real(yb)).all())}
 
 
+def bench_hf_gmres(n=512, restart=30, maxiter=30):
+    """configs[4] as the reference runs it: GPU operator apply, preconditioner applied ON THE HOST through the
+    two-argument in-place callback (src/preconditioner.jl:147-170) -- the Krylov vector crosses PCIe twice per inner
+    step.  The sparsifying factorisation itself is out of scope (and infeasible at 512^3): a diagonal
+    stand-in of the same data movement is used, so this times the boundary, not a preconditioner's quality."""
+    h = 1.0 / n
+    x = -0.5 + h * np.arange(n)
+    k = 64 * np.pi
+    X = np.tile(x, n * n); Y = np.tile(np.repeat(x, n), n); Z = np.repeat(x, n * n)
+    nu = bump(X, Y, Z)
+    M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, k, nu, flags=4)
+    u_inc = torch.from_numpy(np.exp(1j * k * X)).cuda()
+    del X, Y, Z
+    rhs = -(M * u_inc - u_inc)
+    dinv = 1.0 / (1.0 + 0.05 * nu)
+    t_cb = [0.0, 0]
+
+    def Pl(v):
+        t0 = time.time(); v *= dinv; t_cb[0] += time.time() - t0; t_cb[1] += 1
+
+    out = {}
+    for name, kw in [("host preconditioner callback", dict(Pl=Pl)), ("no preconditioner", {})]:
+        u = torch.zeros_like(rhs)
+        t_cb[0], t_cb[1] = 0.0, 0
+        torch.cuda.synchronize(); t0 = time.time()
+        u, hist = lsfc.gmres_(u, M, rhs, restart=restart, reltol=1e-6, maxiter=maxiter, log=True, orth_meth="ClassicalGramSchmidt", **kw)
+        torch.cuda.synchronize(); t = time.time() - t0
+        out[name] = {"iters": hist.iters, "seconds": t, "ms_per_iteration": 1e3 * t / max(hist.iters, 1),
+                     "resnorm_first_last": [float(hist["resnorm"][0]), float(hist["resnorm"][-1])],
+                     "callback_calls": t_cb[1], "host_ms_inside_callback_per_call": 1e3 * t_cb[0] / max(t_cb[1], 1)}
+    return {"config": f"3D n={n} omega=64pi patched symbol, GMRES({restart}) capped at {maxiter} iterations", "solves": out}
+
+
 def bench_host_vectors(n=512):
     """PCIe-inclusive rate: the same apply with HOST-resident x and y (LSFC_MEM_HOST), as the Julia wrapper's `*` does."""
     h = 1.0 / n
@@ -100,6 +133,7 @@ if __name__ == "__main__":
     if "gmres" in what: res.append(bench_gmres())
     if "hf" in what: res.append(bench_hf())
     if "gmres512" in what: res.append(bench_gmres(512))
+    if "hfgmres" in what: res.append(bench_hf_gmres())
     if "host" in what: res.append(bench_host_vectors())
     for r in res:
         print(json.dumps(r), flush=True)
