@@ -64,6 +64,37 @@ def bench_gmres(n=256, restart=30, reltol=1e-6):
     return {"config": f"3D n={n} GMRES({restart}) reltol={reltol:g}", "plan_seconds": t_plan, "apply_ms": ms, "solves": out}
 
 
+def bench_small():
+    """launch-latency territory: the reference's own example sizes (2D n=128 configs[0], 3D n=48 example3D.jl:20)"""
+    out = []
+    for dim, n in [(2, 128), (2, 256), (3, 48), (3, 64)]:
+        if dim == 2:
+            h = 1.0 / (n - 1); x = -0.5 + h * np.arange(n); k = 10 * np.pi if n == 128 else 1.0 / h
+            M = lsfc.buildFastConvolution(x, x, h, k, lambda X, Y: bump(X, Y), quadRule="Greengard_Vico")
+            X = np.tile(x, n)
+        else:
+            h = 1.0 / n; x = -0.5 + h * np.arange(n); k = 1.0 / h
+            X = np.tile(x, n * n); Y = np.tile(np.repeat(x, n), n); Z = np.repeat(x, n * n)
+            M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, k, bump(X, Y, Z))
+        u_inc = torch.from_numpy(np.exp(1j * k * X)).cuda()
+        rhs = -(M * u_inc - u_inc)
+        yb = torch.empty_like(rhs)
+        lsfc.time_apply(M, rhs, yb, 50)
+        us = 1e3 * min(lsfc.time_apply(M, rhs, yb, 500) / 500 for _ in range(3))
+        r = {"config": f"{dim}D n={n}", "pipeline": M.pipeline, "apply_us": us}
+        for orth in ["ModifiedGramSchmidt", "ClassicalGramSchmidt"]:
+            best = None
+            for _ in range(3):
+                u = torch.zeros_like(rhs)
+                torch.cuda.synchronize(); t0 = time.time()
+                u, hist = lsfc.gmres_(u, M, rhs, restart=30, reltol=1e-10, maxiter=60, log=True, orth_meth=orth)
+                torch.cuda.synchronize(); t = time.time() - t0
+                best = t if best is None else min(best, t)
+            r[orth] = {"iters": hist.iters, "us_per_iteration": 1e6 * best / max(hist.iters, 1)}
+        out.append(r)
+    return out
+
+
 def bench_hf(n=512):
     h = 1.0 / n
     x = -0.5 + h * np.arange(n)
@@ -133,6 +164,7 @@ if __name__ == "__main__":
     if "gmres" in what: res.append(bench_gmres())
     if "hf" in what: res.append(bench_hf())
     if "gmres512" in what: res.append(bench_gmres(512))
+    if "small" in what: res.extend(bench_small())
     if "hfgmres" in what: res.append(bench_hf_gmres())
     if "host" in what: res.append(bench_host_vectors())
     for r in res:
