@@ -13,4 +13,17 @@ using Cfg2048 = Cfg<2048, 128, 16, 16, 8>;
 // four-stage, 8 elements per thread: half the registers of Cfg1024 for one more LDS exchange.  Measured slower on
 // MI355X (profiles/r01_experiment_e8_four_stage.log); kept as the tested instance of the 4-stage machinery.
 using Cfg1024S = Cfg<1024, 128, 8, 8, 4, 4>;
+// lines with one factor 3 (L = 3 * 2^k): the radix carrying it is the first one, 12 or 24 elements per thread
+using Cfg48   = Cfg<48,    4, 12, 4>;
+using Cfg96   = Cfg<96,    8, 12, 4, 2>;
+using Cfg192  = Cfg<192,  16, 12, 4, 4>;
+using Cfg384  = Cfg<384,  16, 24, 4, 4>;
+using Cfg768  = Cfg<768,  32, 24, 8, 4>;
+using Cfg1536 = Cfg<1536, 64, 24, 8, 8>;
+// lines with one factor 5 (L = 5 * 2^k): first radix 20, 20 elements per thread
+using Cfg80   = Cfg<80,    4, 20, 4>;
+using Cfg160  = Cfg<160,   8, 20, 4, 2>;
+using Cfg320  = Cfg<320,  16, 20, 4, 4>;
+using Cfg640  = Cfg<640,  32, 20, 4, 4, 2>;
+using Cfg1280 = Cfg<1280, 64, 20, 4, 4, 4>;
 }} // namespace

@@ -34,9 +34,34 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
 }
 __device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
 
-// exp(-DIR * 2*pi*i * K / R) * a for compile-time K, R in {2,4,8,16,32}.
+// exp(-DIR * 2*pi*i * K / R) * a for compile-time K and R: any divisor of 32 (power-of-two lines), of 24 (lines with
+// one factor 3) or of 40 (one factor 5).  Constants are the correctly rounded cosines / sines of the 32-, 24- and
+// 40-gon.
+template <int B> struct NGon;
+template <> struct NGon<24> {
+    static constexpr double C[24] = { 1.0, 0.9659258262890683, 0.8660254037844386, 0.7071067811865476, 0.5, 0.25881904510252074, 0.0, -0.25881904510252074, -0.5, -0.7071067811865476, -0.8660254037844386, -0.9659258262890683, -1.0, -0.9659258262890683, -0.8660254037844386, -0.7071067811865476, -0.5, -0.25881904510252074, 0.0, 0.25881904510252074, 0.5, 0.7071067811865476, 0.8660254037844386, 0.9659258262890683 };
+    static constexpr double S[24] = { 0.0, 0.25881904510252074, 0.5, 0.7071067811865476, 0.8660254037844386, 0.9659258262890683, 1.0, 0.9659258262890683, 0.8660254037844386, 0.7071067811865476, 0.5, 0.25881904510252074, 0.0, -0.25881904510252074, -0.5, -0.7071067811865476, -0.8660254037844386, -0.9659258262890683, -1.0, -0.9659258262890683, -0.8660254037844386, -0.7071067811865476, -0.5, -0.25881904510252074 };
+};
+template <> struct NGon<40> {
+    static constexpr double C[40] = { 1.0, 0.9876883405951378, 0.9510565162951535, 0.8910065241883679, 0.8090169943749475, 0.7071067811865476, 0.5877852522924731, 0.4539904997395468, 0.30901699437494745, 0.15643446504023087, 0.0, -0.15643446504023087, -0.30901699437494745, -0.4539904997395468, -0.5877852522924731, -0.7071067811865476, -0.8090169943749475, -0.8910065241883679, -0.9510565162951535, -0.9876883405951378, -1.0, -0.9876883405951378, -0.9510565162951535, -0.8910065241883679, -0.8090169943749475, -0.7071067811865476, -0.5877852522924731, -0.4539904997395468, -0.30901699437494745, -0.15643446504023087, 0.0, 0.15643446504023087, 0.30901699437494745, 0.4539904997395468, 0.5877852522924731, 0.7071067811865476, 0.8090169943749475, 0.8910065241883679, 0.9510565162951535, 0.9876883405951378 };
+    static constexpr double S[40] = { 0.0, 0.15643446504023087, 0.30901699437494745, 0.4539904997395468, 0.5877852522924731, 0.7071067811865476, 0.8090169943749475, 0.8910065241883679, 0.9510565162951535, 0.9876883405951378, 1.0, 0.9876883405951378, 0.9510565162951535, 0.8910065241883679, 0.8090169943749475, 0.7071067811865476, 0.5877852522924731, 0.4539904997395468, 0.30901699437494745, 0.15643446504023087, 0.0, -0.15643446504023087, -0.30901699437494745, -0.4539904997395468, -0.5877852522924731, -0.7071067811865476, -0.8090169943749475, -0.8910065241883679, -0.9510565162951535, -0.9876883405951378, -1.0, -0.9876883405951378, -0.9510565162951535, -0.8910065241883679, -0.8090169943749475, -0.7071067811865476, -0.5877852522924731, -0.4539904997395468, -0.30901699437494745, -0.15643446504023087 };
+};
 template <int R, int K, int DIR> struct MulW {
     __device__ __forceinline__ static cplx apply(cplx a) {
+        if constexpr (32 % R != 0) {
+            constexpr int B = (24 % R == 0) ? 24 : 40;
+            static_assert(B % R == 0, "radix must divide 32, 24 or 40");
+            constexpr int i = ((K * (B / R)) % B + B) % B;
+            if constexpr (i == 0) return a;
+            else if constexpr (i == B / 2) return make_double2(-a.x, -a.y);
+            else if constexpr (i == B / 4) return DIR > 0 ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x);
+            else if constexpr (i == 3 * B / 4) return DIR > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+            else {
+                constexpr double wr = NGon<B>::C[i];
+                constexpr double wi = (DIR > 0 ? -1.0 : 1.0) * NGon<B>::S[i];
+                return make_double2(fma(-a.y, wi, a.x * wr), fma(a.x, wi, a.y * wr));
+            }
+        } else {
         constexpr int idx = ((K * (32 / R)) % 32 + 32) % 32;
         constexpr double C32[32] = { 1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254523567, 0.70710678118654757274, 0.55557023301960228867, 0.38268343236508983729, 0.19509032201612833135, 0.00000000000000006123, -0.19509032201612819257, -0.38268343236508972627, -0.55557023301960195560, -0.70710678118654746172, -0.83146961230254534669, -0.92387953251128673848, -0.98078528040323043058, -1.00000000000000000000, -0.98078528040323043058, -0.92387953251128684951, -0.83146961230254545772, -0.70710678118654768376, -0.55557023301960217765, -0.38268343236509033689, -0.19509032201612866442, -0.00000000000000018370, 0.19509032201612830359, 0.38268343236509000382, 0.55557023301960184458, 0.70710678118654735069, 0.83146961230254523567, 0.92387953251128651644, 0.98078528040323031956 };
         constexpr double S32[32] = { 0.00000000000000000000, 0.19509032201612824808, 0.38268343236508978178, 0.55557023301960217765, 0.70710678118654746172, 0.83146961230254523567, 0.92387953251128673848, 0.98078528040323043058, 1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254545772, 0.70710678118654757274, 0.55557023301960217765, 0.38268343236508989280, 0.19509032201612860891, 0.00000000000000012246, -0.19509032201612835911, -0.38268343236508967076, -0.55557023301960195560, -0.70710678118654746172, -0.83146961230254523567, -0.92387953251128651644, -0.98078528040323031956, -1.00000000000000000000, -0.98078528040323043058, -0.92387953251128662746, -0.83146961230254545772, -0.70710678118654768376, -0.55557023301960217765, -0.38268343236509039240, -0.19509032201612871993 };
@@ -55,6 +80,7 @@ template <int R, int K, int DIR> struct MulW {
             constexpr double wi = (DIR > 0 ? -1.0 : 1.0) * S32[idx];
             return make_double2(fma(-a.y, wi, a.x * wr), fma(a.x, wi, a.y * wr));
         }
+        }
     }
 };
 
@@ -66,6 +92,33 @@ template <int DIR> struct Dft<1, DIR> { __device__ __forceinline__ static void r
 template <int DIR> struct Dft<2, DIR> {
     __device__ __forceinline__ static void run(cplx (&a)[2]) {
         const cplx s = cadd(a[0], a[1]), d = csub(a[0], a[1]); a[0] = s; a[1] = d;
+    }
+};
+
+// multiply by -i (DIR > 0) or +i (DIR < 0)
+template <int DIR> __device__ __forceinline__ cplx mul_mi(cplx a) { return DIR > 0 ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x); }
+template <int DIR> struct Dft<3, DIR> {
+    __device__ __forceinline__ static void run(cplx (&a)[3]) {
+        constexpr double h = 0.8660254037844386;         // sin(2 pi / 3)
+        const cplx t1 = cadd(a[1], a[2]);
+        const cplx t2 = make_double2(fma(-0.5, t1.x, a[0].x), fma(-0.5, t1.y, a[0].y));
+        const cplx d = csub(a[1], a[2]);
+        const cplx s = mul_mi<DIR>(make_double2(h * d.x, h * d.y));
+        a[0] = cadd(a[0], t1); a[1] = cadd(t2, s); a[2] = csub(t2, s);
+    }
+};
+template <int DIR> struct Dft<5, DIR> {
+    __device__ __forceinline__ static void run(cplx (&a)[5]) {
+        constexpr double c1 = 0.30901699437494745, c2 = -0.8090169943749475;    // cos(2 pi/5), cos(4 pi/5)
+        constexpr double s1 = 0.9510565162951535, s2 = 0.5877852522924731;      // sin(2 pi/5), sin(4 pi/5)
+        const cplx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+        const cplx m1 = make_double2(fma(c2, t2.x, fma(c1, t1.x, a[0].x)), fma(c2, t2.y, fma(c1, t1.y, a[0].y)));
+        const cplx m2 = make_double2(fma(c1, t2.x, fma(c2, t1.x, a[0].x)), fma(c1, t2.y, fma(c2, t1.y, a[0].y)));
+        const cplx n1 = mul_mi<DIR>(make_double2(fma(s2, t4.x, s1 * t3.x), fma(s2, t4.y, s1 * t3.y)));
+        const cplx n2 = mul_mi<DIR>(make_double2(fma(-s1, t4.x, s2 * t3.x), fma(-s1, t4.y, s2 * t3.y)));
+        a[0] = cadd(a[0], cadd(t1, t2));
+        a[1] = cadd(m1, n1); a[4] = csub(m1, n1);
+        a[2] = cadd(m2, n2); a[3] = csub(m2, n2);
     }
 };
 
@@ -130,6 +183,17 @@ __device__ __forceinline__ void dft_halfout(cplx (&a)[R]) {
 // w[k] = w1^k for k = 1..R-1 by a depth-<=4 product tree (error ~ 4 ulp).
 template <int R> __device__ __forceinline__ void twiddle_powers(cplx w1, cplx (&w)[R]) {
     w[0] = make_double2(1.0, 0.0);
+    if constexpr ((R & (R - 1)) != 0) {
+        // radices with an odd factor (3, 6, 12, 24, 5, 10, 20): the same tree, w[k] = w[p] * w[k - p] with p the
+        // largest power of two <= k
+        if constexpr (R > 1) w[1] = w1;
+#pragma unroll
+        for (int k = 2; k < R; ++k) {
+            int p = 1; while (2 * p <= k) p *= 2;
+            w[k] = (k == p) ? cmul(w[p / 2], w[p / 2]) : cmul(w[p], w[k - p]);
+        }
+        return;
+    }
     if constexpr (R > 1) w[1] = w1;
     if constexpr (R > 2) { w[2] = cmul(w1, w1); w[3] = cmul(w[2], w1); }
     if constexpr (R > 4) { w[4] = cmul(w[2], w[2]); w[5] = cmul(w[4], w1); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]); }

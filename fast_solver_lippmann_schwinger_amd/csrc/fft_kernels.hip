@@ -13,7 +13,7 @@
 //
 // (2D: xfwd -> zfused along y on the natural A1[Lx][m] -> xinv.)
 // The grid sizes n, m, l need not be powers of two: every pass reads only the first n (m, l) entries of a line
-// and zero-fills up to L/2, writes only the first n (m, l) on the way back; L = 2*nextpow2(n) per axis.
+// and zero-fills up to L/2, writes only the first n (m, l) on the way back; L = pruned_best_length(n) per axis.
 // Frequency-side indices are "storage" indices (fft_core.hpp); A2 is tiled so that
 // the eight x'-neighbours of a z-line are interleaved (xi fastest), which makes
 // the largest pass (z: 16 of the 35 complex per point) a pure stream.
@@ -24,16 +24,25 @@
 #include <set>
 #include <utility>
 
+// This file is compiled once per family of line lengths (Makefile: -DLSFC_FAMILY=2 | 3 | 5): the power-of-two lines,
+// the lines with one factor 3 and the lines with one factor 5.  pruned.hip routes each call to the family of its L.
+#ifndef LSFC_FAMILY
+#error "compile with -DLSFC_FAMILY=2, 3 or 5"
+#endif
+#define LSFC_CAT2(a, b) a##b
+#define LSFC_CAT(a, b) LSFC_CAT2(a, b)
+#define FAM(name) LSFC_CAT(LSFC_CAT(name, _f), LSFC_FAMILY)
+
 namespace lsfc {
 using namespace fft;
 
 static constexpr int XB = 8;           // x' lines per strided workgroup: 8 * 16 B = one 128-B line
 
-// EXACT: n == L/2 (power-of-two grid): the end-of-line predicates compile away
+// EXACT: n == L/2 (the grid fills the line): the end-of-line predicates compile away
 template <class C, int LPW, bool SPLIT, bool EXACT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __restrict__ out,
-            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp, int n, int64_t bstride) {
+            const cplx* __restrict__ tw, int64_t nlines, int logW, int wmask, int Wp, int n, int64_t bstride) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -55,12 +64,12 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
     fft_forward<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
     if (valid) {
         // storage index s of this line goes to chunk s>>logW (one chunk per destination rank of the slab
-        // transpose; a single chunk of width L on one GPU): out[chunk][line][s & (W-1)], row pitch Wp >= W
-        const int64_t W = (int64_t)1 << logW;
+        // transpose; a single chunk of width L on one GPU: logW = 31, wmask = all ones): out[chunk][line][s & wmask],
+        // row pitch Wp >= W
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int s = t + T * e;
-            out[(int64_t)(s >> logW) * bstride + line * Wp + (s & (W - 1))] = v[e];
+            out[(int64_t)(s >> logW) * bstride + line * Wp + (s & wmask)] = v[e];
         }
     }
 }
@@ -68,7 +77,7 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
 template <class C, int LPW, bool SPLIT, bool EXACT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alpha, double beta,
-            const cplx* __restrict__ tw, int64_t nlines, int logW, int Wp, int n, int64_t bstride) {
+            const cplx* __restrict__ tw, int64_t nlines, int logW, int wmask, int Wp, int n, int64_t bstride) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -76,12 +85,11 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
     const int64_t line = (int64_t)blockIdx.x * LPW + ll;
     const bool valid = line < nlines;
     const int64_t lc = valid ? line : nlines - 1;
-    const int64_t W = (int64_t)1 << logW;
     cplx v[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int s = t + T * e;
-        v[e] = in[(int64_t)(s >> logW) * bstride + lc * Wp + (s & (W - 1))];
+        v[e] = in[(int64_t)(s >> logW) * bstride + lc * Wp + (s & wmask)];
     }
     fft_inverse<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
     if (valid) {
@@ -271,21 +279,21 @@ template <class C> struct Tune {
     static constexpr int LINES = (C::T * XB <= 512 || (C::E <= 8 && C::T * XB <= 1024)) ? XB : 512 / C::T;
 };
 
-template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int logW, int Wp, int n, int64_t bstride, hipStream_t st) {
+template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int logW, int wmask, int Wp, int n, int64_t bstride, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = (n == C::L / 2) ? k_xfwd<C, LPW, SPLIT, true> : k_xfwd<C, LPW, SPLIT, false>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW, Wp, n, bstride);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW, wmask, Wp, n, bstride);
 }
-template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int logW, int Wp, int n, int64_t bstride, hipStream_t st) {
+template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int logW, int wmask, int Wp, int n, int64_t bstride, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = (n == C::L / 2) ? k_xinv<C, LPW, SPLIT, true> : k_xinv<C, LPW, SPLIT, false>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW, Wp, n, bstride);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW, wmask, Wp, n, bstride);
 }
 static void ytile(const PrunedTuning& tn, int L, int ngrp, int l, int& TG, int& TZ) {
     // auto (0): all groups x 1 plane, except at L >= 1024 where 32 groups x 8 planes keeps the 128-B chunks that the
@@ -356,12 +364,7 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
                        dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin);
 }
 
-static bool env_flag(const char* name, bool dflt) {
-    const char* v = getenv(name);
-    if (!v || !*v) return dflt;
-    return v[0] == '1' || v[0] == 'y' || v[0] == 't';
-}
-
+#if LSFC_FAMILY == 2
 #define LSFC_DISPATCH_L(L, CALL)                                           \
     switch (L) {                                                           \
     case 32:   { using C = Cfg32;   CALL; } break;                         \
@@ -372,72 +375,84 @@ static bool env_flag(const char* name, bool dflt) {
     case 1024: { using C = Cfg1024; CALL; } break;                         \
     case 2048: { using C = Cfg2048; CALL; } break;                         \
     default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); }
+#elif LSFC_FAMILY == 3
+#define LSFC_DISPATCH_L(L, CALL)                                           \
+    switch (L) {                                                           \
+    case 48:   { using C = Cfg48;   CALL; } break;                         \
+    case 96:   { using C = Cfg96;   CALL; } break;                         \
+    case 192:  { using C = Cfg192;  CALL; } break;                         \
+    case 384:  { using C = Cfg384;  CALL; } break;                         \
+    case 768:  { using C = Cfg768;  CALL; } break;                         \
+    case 1536: { using C = Cfg1536; CALL; } break;                         \
+    default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); }
+#else
+#define LSFC_DISPATCH_L(L, CALL)                                           \
+    switch (L) {                                                           \
+    case 80:   { using C = Cfg80;   CALL; } break;                         \
+    case 160:  { using C = Cfg160;  CALL; } break;                         \
+    case 320:  { using C = Cfg320;  CALL; } break;                         \
+    case 640:  { using C = Cfg640;  CALL; } break;                         \
+    case 1280: { using C = Cfg1280; CALL; } break;                         \
+    default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); }
+#endif
 
-bool pruned_length_supported(int64_t L) {
-    return L == 32 || L == 64 || L == 128 || L == 256 || L == 512 || L == 1024 || L == 2048;
-}
-
-void pruned_perm(int L, int* freq_of_storage) {
+void FAM(pruned_perm)(int L, int* freq_of_storage) {
     LSFC_DISPATCH_L(L, perm_table<C>(freq_of_storage));
 }
 
-PrunedTuning pruned_default_tuning() {
-    PrunedTuning t;
-    t.split_x = env_flag("LSFC_SPLIT_X", true);
-    t.split_s = env_flag("LSFC_SPLIT_S", true);
-    if (const char* v = getenv("LSFC_SPLIT_Z")) t.split_z = atoi(v);
-    if (const char* v = getenv("LSFC_PAD1")) t.pad1 = atoi(v);
-    if (const char* v = getenv("LSFC_PAD2")) t.pad2 = atoi(v);
-    if (const char* v = getenv("LSFC_Z_HALF")) t.z_half = atoi(v);
-    if (const char* v = getenv("LSFC_TW_LDS")) t.tw_lds = atoi(v);
-    if (const char* v = getenv("LSFC_SYM_PREFETCH")) t.sym_prefetch = atoi(v);
-    if (const char* v = getenv("LSFC_YTILE_G")) t.ytile_g = atoi(v);
-    if (const char* v = getenv("LSFC_YTILE_Z")) t.ytile_z = atoi(v);
-    return t;
+// chunk addressing of the x passes: power-of-two chunk widths by shift and mask; a single chunk (W = L) of any length
+static void chunk_bits(int L, int W, int& logW, int& wmask) {
+    if (W == L) { logW = 31; wmask = 0x7fffffff; return; }
+    int l = 0; while ((1 << l) < W) ++l;
+    LSFC_REQUIRE((1 << l) == W, "chunk width %d is not a power of two", W);
+    logW = l; wmask = W - 1;
 }
 
-static int log2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; LSFC_REQUIRE((1 << l) == v, "chunk width %d is not a power of two", v); return l; }
-
-void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
-    const int logW = log2_exact(W);
+void FAM(pruned_xfwd)(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
+    int logW, wmask; chunk_bits(L, W, logW, wmask);
     if (bstride <= 0) bstride = (int64_t)Wp * nlines;       // dense chunks: [chunk][line][Wp]
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, logW, Wp, n, bstride, st))); }
-    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, logW, Wp, n, bstride, st))); }
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, logW, wmask, Wp, n, bstride, st))); }
+    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, logW, wmask, Wp, n, bstride, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
-    const int logW = log2_exact(W);
+void FAM(pruned_xinv)(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
+    int logW, wmask; chunk_bits(L, W, logW, wmask);
     if (bstride <= 0) bstride = (int64_t)Wp * nlines;       // dense chunks: [chunk][line][Wp]
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, n, bstride, st))); }
-    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, logW, Wp, n, bstride, st))); }
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, logW, wmask, Wp, n, bstride, st))); }
+    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, logW, wmask, Wp, n, bstride, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
-    if (tn.split_s) { LSFC_DISPATCH_L(L, (yfwd_t<C, true, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
+void FAM(pruned_yfwd)(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
+    size_t full_lds = 0;
+    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::LINES, 3, false>::line_elems(C::L) * Tune<C>::LINES * 16));
+    if (tn.split_s || full_lds > (size_t)160 * 1024) { LSFC_DISPATCH_L(L, (yfwd_t<C, true, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
     else            { LSFC_DISPATCH_L(L, (yfwd_t<C, false, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
-    if (tn.split_s) { LSFC_DISPATCH_L(L, (yinv_t<C, true, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
+void FAM(pruned_yinv)(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
+    size_t full_lds = 0;
+    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::LINES, 3, false>::line_elems(C::L) * Tune<C>::LINES * 16));
+    if (tn.split_s || full_lds > (size_t)160 * 1024) { LSFC_DISPATCH_L(L, (yinv_t<C, true, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
     else            { LSFC_DISPATCH_L(L, (yinv_t<C, false, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
     LSFC_HIP(hipGetLastError());
 }
-int pruned_twfull_len(int L) {
+int FAM(pruned_twfull_len)(int L) {
     int len = 0;
     LSFC_DISPATCH_L(L, len = C::TWLEN);
     return len;
 }
-void pruned_twfull(int L, const cplx* tw, cplx* out) {
+void FAM(pruned_twfull)(int L, const cplx* tw, cplx* out) {
     LSFC_DISPATCH_L(L, twfull_table<C>(out, tw));
 }
 
-void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
+void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, const int2* ytab,
                    const int* zm, int nin, hipStream_t st) {
 #define LSFC_ZF(SP, PF) do { if (zm) { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); } \
                              else    { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, false>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); } } while (0)
     // auto (-1): half-tile, split exchanges, symbol prefetch -- 6.95 -> 6.6 ms at 512^3 (profiles/r01_experiment_half_tile.log)
     // with the z-even half symbol the full-tile form wins (6.05 ms, profiles/r01_experiment_even_z.log)
+#if LSFC_FAMILY == 2
     const int zh = tn.z_half >= 0 ? tn.z_half : (zm ? 0 : 2);
     if (L == 1024 && zh > 0 && dLine == 8 && ((int64_t)(Lx / XB) * nouter) % 8 == 0) {
         using C = Cfg1024;
@@ -453,11 +468,25 @@ void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, c
         LSFC_HIP(hipGetLastError());
         return;
     }
+#endif
     // auto (-1): measured on MI355X -- at L >= 1024 (16 elements/thread, 2 waves/SIMD either way) whole-complex
     // exchanges + symbol prefetch win (7.4 -> 6.7 ms at 512^3); below, split exchanges without prefetch (more waves)
-    const bool e16 = L >= 1024;
-    const bool sp = tn.split_z >= 0 ? tn.split_z != 0 : !e16;
+    // mixed-radix lines (profiles/r01_experiment_mixed_radix_knobs.log): the symbol prefetch pays from L = 320 on
+    // (z pass -15..-30 %), whole-complex exchanges on the factor-3 lines from L = 384; the 1536-point line (24
+    // elements per thread in 512-thread workgroups) has no registers left for the prefetch
+#if LSFC_FAMILY == 2
+    const bool e16 = L >= 1024, full = e16;
+#elif LSFC_FAMILY == 3
+    const bool e16 = L >= 384 && L < 1536, full = L >= 384;
+#else
+    const bool e16 = L >= 320, full = false;
+#endif
+    bool sp = tn.split_z >= 0 ? tn.split_z != 0 : !full;
     const bool pf = tn.sym_prefetch >= 0 ? tn.sym_prefetch != 0 : e16;
+    // whole-complex exchange buffers of the longest lines exceed the 160 KiB of LDS: those run split
+    size_t full_lds = 0;
+    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::LINES, 3, false>::line_elems(C::L) * Tune<C>::LINES * 16));
+    if (full_lds > (size_t)160 * 1024) sp = true;
     if (sp) { if (pf) { LSFC_ZF(true, true); } else { LSFC_ZF(true, false); } }
     else    { if (pf) { LSFC_ZF(false, true); } else { LSFC_ZF(false, false); } }
 #undef LSFC_ZF

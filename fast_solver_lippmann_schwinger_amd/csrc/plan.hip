@@ -110,29 +110,29 @@ void plan_make_twiddles(lsfc_plan* p, int axis, int L) {
     LSFC_HIP(hipMemcpy(p->twl[axis].p, full.data(), full.size() * sizeof(cplx), hipMemcpyHostToDevice));
 }
 
-static int next_pow2(int v) { int p2 = 1; while (p2 < v) p2 <<= 1; return p2; }
-
-// The hand-written pipeline works on L = 2*nextpow2(n) per axis (the grid itself may have any size: lines are
-// zero-extended in registers).  It is chosen unless the power-of-two embedding would more than quadruple the
-// number of grid points, where the monolithic rocFFT transform on the exact 2n grid is the better deal.
+// The hand-written pipeline works on L = the smallest of 2^k, 3*2^k, 5*2^k that is >= 2n, per axis (the grid itself
+// may have any size: lines are zero-extended in registers).  It is chosen unless that embedding would more than
+// quadruple the number of grid points (tiny or very elongated grids), where the monolithic rocFFT transform on the
+// exact 2n grid is the better deal.
 static bool pruned_eligible(const lsfc_plan* p) {
     if (p->flags & (LSFC_FLAG_FORCE_ROCFFT | LSFC_FLAG_LITERAL_PAD)) return false;
     double ratio = 1.0;
     for (int d = 0; d < p->ndim; ++d) {
-        const int n2 = std::max(16, next_pow2(p->dims[d]));
-        if (!pruned_length_supported(2 * (int64_t)n2)) return false;
-        ratio *= (double)n2 / (double)p->dims[d];
+        const int L = pruned_best_length(p->dims[d]);
+        if (L == 0) return false;
+        if (p->ndim == 3 && d == 2 && L == 2048) return false;     // the fused z pass needs whole 8-line tiles in LDS
+        ratio *= (double)L / (2.0 * (double)p->dims[d]);
     }
     return ratio <= 4.0;
 }
 
-// working padded grid of the reduced pipelines: 2*nextpow2(n) (pruned) or 2n (rocFFT)
+// working padded grid of the reduced pipelines: pruned_best_length(n) (pruned) or 2n (rocFFT)
 void plan_choose_reduced_grid(lsfc_plan* p) {
     const bool pr = pruned_eligible(p);
     for (int d = 0; d < 3; ++d) {
         p->crop[d] = 0;
         if (d >= p->ndim) p->pads[d] = 1;
-        else p->pads[d] = pr ? 2 * std::max(16, next_pow2(p->dims[d])) : 2 * p->dims[d];
+        else p->pads[d] = pr ? pruned_best_length(p->dims[d]) : 2 * p->dims[d];
     }
     p->pipeline = pr ? lsfc_plan::PRUNED : lsfc_plan::ROCFFT_REDUCED;
 }

@@ -121,7 +121,7 @@ inline void plan_apply_dev(lsfc_plan* p, const cplx* x, cplx* y) { plan_convolve
 void plan_finish_literal(lsfc_plan* p, const cplx* Gd, bool centred);
 //   reduce a (pe,me,le) symbol (centred or FFT order) to the (2n,2m,2l) grid and pick the pipeline
 void plan_finish_reduce(lsfc_plan* p, DevBuf<cplx>& Gd, const int lit[3], bool centred, const int kernel_origin[3]);
-//   picks pruned (2*nextpow2(n)) or rocFFT (2n) and sets p->pads / p->pipeline
+//   picks pruned (pruned_best_length(n)) or rocFFT (2n) and sets p->pads / p->pipeline
 void plan_choose_reduced_grid(lsfc_plan* p);
 //   G2 natural FFT order on the (2n,2m,2l) grid, unscaled
 void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2);

@@ -1,0 +1,97 @@
+// Front end of the hand-written axis passes: routes every call to the family of its line length (fft_kernels.hip is
+// compiled once per family: power-of-two lines, lines with one factor 3, lines with one factor 5).
+#include "pruned.hpp"
+#include <cstdlib>
+
+namespace lsfc {
+
+#define LSFC_FAMILY_DECLS(F)                                                                                                   \
+    void pruned_xfwd_f##F(int, const PrunedTuning&, const cplx*, const double*, cplx*, const cplx*, int64_t, int, int, int, hipStream_t, int64_t); \
+    void pruned_xinv_f##F(int, const PrunedTuning&, const cplx*, const cplx*, cplx*, double, double, const cplx*, int64_t, int, int, int, hipStream_t, int64_t); \
+    void pruned_yfwd_f##F(int, const PrunedTuning&, const cplx*, cplx*, const cplx*, int, int, int, int, int, hipStream_t);     \
+    void pruned_yinv_f##F(int, const PrunedTuning&, const cplx*, cplx*, const cplx*, int, int, int, int, int, hipStream_t);     \
+    void pruned_zfused_f##F(int, const PrunedTuning&, cplx*, const cplx*, const cplx*, const cplx*, int, int, int64_t, int64_t, int64_t, \
+                            int64_t, int64_t, int64_t, const int2*, const int*, int, hipStream_t);                              \
+    void pruned_perm_f##F(int, int*);                                                                                           \
+    int pruned_twfull_len_f##F(int);                                                                                            \
+    void pruned_twfull_f##F(int, const cplx*, cplx*);
+LSFC_FAMILY_DECLS(2)
+LSFC_FAMILY_DECLS(3)
+LSFC_FAMILY_DECLS(5)
+
+// 2: L = 2^k (32..2048);  3: L = 3 * 2^k (48..1536);  5: L = 5 * 2^k (80..1280);  0: not supported
+static int family(int64_t L) {
+    if (L < 32 || L > 2048) return 0;
+    int64_t v = L; while (v % 2 == 0) v /= 2;
+    if (v == 1) return 2;
+    if (v == 3) return L >= 48 && L <= 1536 ? 3 : 0;
+    if (v == 5) return L >= 80 && L <= 1280 ? 5 : 0;
+    return 0;
+}
+bool pruned_length_supported(int64_t L) { return family(L) != 0; }
+
+int pruned_best_length(int64_t n) {
+    // LSFC_POW2_ONLY=1 (developer switch): power-of-two lines only, for A/B timing of the mixed-radix lines
+    const char* e = getenv("LSFC_POW2_ONLY");
+    const bool pow2_only = e && e[0] == '1';
+    for (int64_t L = (2 * n > 32 ? 2 * n : 32); L <= 2048; ++L) if (family(L) && (!pow2_only || family(L) == 2)) return (int)L;
+    return 0;
+}
+
+#define LSFC_ROUTE(L, NAME, ...)                                            \
+    switch (family(L)) {                                                    \
+    case 2: NAME##_f2(__VA_ARGS__); break;                                  \
+    case 3: NAME##_f3(__VA_ARGS__); break;                                  \
+    case 5: NAME##_f5(__VA_ARGS__); break;                                  \
+    default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); }
+
+void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
+    LSFC_ROUTE(L, pruned_xfwd, L, tn, x, nu, out, tw, nlines, W, Wp, n, st, bstride);
+}
+void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
+    LSFC_ROUTE(L, pruned_xinv, L, tn, in, xo, y, alpha, beta, tw, nlines, W, Wp, n, st, bstride);
+}
+void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
+    LSFC_ROUTE(L, pruned_yfwd, L, tn, a1, a2, tw, Lx, m, l, p1, p2, st);
+}
+void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
+    LSFC_ROUTE(L, pruned_yinv, L, tn, a2, a1, tw, Lx, m, l, p1, p2, st);
+}
+void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
+                   int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, const int2* ytab,
+                   const int* zm, int nin, hipStream_t st) {
+    LSFC_ROUTE(L, pruned_zfused, L, tn, data, sym, tw, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
+}
+void pruned_perm(int L, int* freq_of_storage) { LSFC_ROUTE(L, pruned_perm, L, freq_of_storage); }
+int pruned_twfull_len(int L) {
+    switch (family(L)) {
+    case 2: return pruned_twfull_len_f2(L);
+    case 3: return pruned_twfull_len_f3(L);
+    case 5: return pruned_twfull_len_f5(L);
+    default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", L);
+    }
+}
+void pruned_twfull(int L, const cplx* tw, cplx* out) { LSFC_ROUTE(L, pruned_twfull, L, tw, out); }
+
+static bool env_flag(const char* name, bool dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return v[0] == '1' || v[0] == 'y' || v[0] == 't';
+}
+
+PrunedTuning pruned_default_tuning() {
+    PrunedTuning t;
+    t.split_x = env_flag("LSFC_SPLIT_X", true);
+    t.split_s = env_flag("LSFC_SPLIT_S", true);
+    if (const char* v = getenv("LSFC_SPLIT_Z")) t.split_z = atoi(v);
+    if (const char* v = getenv("LSFC_PAD1")) t.pad1 = atoi(v);
+    if (const char* v = getenv("LSFC_PAD2")) t.pad2 = atoi(v);
+    if (const char* v = getenv("LSFC_Z_HALF")) t.z_half = atoi(v);
+    if (const char* v = getenv("LSFC_TW_LDS")) t.tw_lds = atoi(v);
+    if (const char* v = getenv("LSFC_SYM_PREFETCH")) t.sym_prefetch = atoi(v);
+    if (const char* v = getenv("LSFC_YTILE_G")) t.ytile_g = atoi(v);
+    if (const char* v = getenv("LSFC_YTILE_Z")) t.ytile_z = atoi(v);
+    return t;
+}
+
+} // namespace lsfc

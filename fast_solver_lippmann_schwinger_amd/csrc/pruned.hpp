@@ -17,6 +17,8 @@ struct PrunedTuning {
 };
 
 bool pruned_length_supported(int64_t L);
+// smallest supported line length L >= max(2n, 32): L = 2^k, 3 * 2^k or 5 * 2^k (0: none up to 2048)
+int pruned_best_length(int64_t n);
 // n (x passes), m (y passes), nin (fused pass): the actual grid size along the transformed axis, <= L/2; entries beyond
 // it are treated as zero on the way in and not written on the way back.
 // W = chunk width of the x'-storage axis in the xfwd output / xinv input: out[s / W][line][s % W] (W = L on one GPU;

@@ -71,7 +71,7 @@ __global__ void k_crop_z(const cplx* __restrict__ U, cplx* __restrict__ T2, int6
 
 void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2) {
     const int n = p->dims[0], m = p->dims[1], l = p->dims[2];
-    // literal lattice P = 4n (src/FastConvolution3D.jl:79-81); working grid Q = p->pads (2n, or 2*nextpow2(n) <= 4n)
+    // literal lattice P = 4n (src/FastConvolution3D.jl:79-81); working grid Q = p->pads (2n, or pruned_best_length(n) <= 4n)
     const int P0 = 4 * n, P1 = 4 * m, P2 = 4 * l, Q0 = p->pads[0], Q1 = p->pads[1], Q2 = p->pads[2];
     LSFC_REQUIRE(Q0 <= P0 && Q1 <= P1 && Q2 <= P2 && Q0 >= 2 * n && Q1 >= 2 * m && Q2 >= 2 * l, "internal: working grid outside [2n, 4n]");
     const double Lp = 4.0 * box, L = 1.8 * box, k = p->omega;       // src/FastConvolution3D.jl:72-73

@@ -77,9 +77,11 @@ template <class C, class LL> static double run_cfg(const char* name, bool prune)
     std::vector<int> perm(L); perm_table<C>(perm.data());
     std::vector<char> seen(L, 0); for (int s = 0; s < L; ++s) { if (perm[s] < 0 || perm[s] >= L || seen[perm[s]]) { printf("%s: perm not a bijection\n", name); return 1; } seen[perm[s]] = 1; }
     long double err = 0, nrm = 0;
+    std::vector<lc> wl(L);                            // exp(-2 pi i j / L) in long double, for the naive reference DFT
+    for (int j = 0; j < L; ++j) { long double a = -2.0L * M_PIl * j / L; wl[j] = lc(cosl(a), sinl(a)); }
     for (int l = 0; l < nlines; ++l) {
         std::vector<lc> X(L);
-        for (int k = 0; k < L; ++k) { lc acc(0, 0); for (int j = 0; j < L; ++j) { long double a = -2.0L * M_PIl * ((long long)j * k % L) / L; acc += xin[l][j] * lc(cosl(a), sinl(a)); } X[k] = acc; }
+        for (int k = 0; k < L; ++k) { lc acc(0, 0); for (int j = 0; j < L; ++j) acc += xin[l][j] * wl[(long long)j * k % L]; X[k] = acc; }
         for (int t = 0; t < C::T; ++t) for (int e = 0; e < C::E; ++e) {
             cplx g = regs[l * C::T + t][e]; lc ref = X[perm[t + C::T * e]];
             err += std::norm(lc(g.x, g.y) - ref); nrm += std::norm(ref);
@@ -113,6 +115,8 @@ int main() {
     g_twfull = pass == 1;
     printf("---- stage twiddles: %s\n", g_twfull ? "full table" : "product tree");
     RUN(Cfg32); RUN(Cfg64); RUN(Cfg128); RUN(Cfg256); RUN(Cfg512); RUN(Cfg1024); RUN(Cfg2048); RUN(Cfg1024S);
+    RUN(Cfg48); RUN(Cfg96); RUN(Cfg192); RUN(Cfg384); RUN(Cfg768); RUN(Cfg1536);
+    RUN(Cfg80); RUN(Cfg160); RUN(Cfg320); RUN(Cfg640); RUN(Cfg1280);
     }
     printf("worst=%.3e\n", worst);
     return worst < 1e-13 ? 0 : 1;

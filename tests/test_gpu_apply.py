@@ -14,6 +14,13 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 LITERAL, FORCE_ROCFFT, PATCH = 1, 2, 4
+# padded line lengths of the hand-written pipeline (csrc/pruned.hip): 2^k, 3*2^k, 5*2^k
+LENGTHS = sorted([32, 64, 128, 256, 512, 1024, 2048, 48, 96, 192, 384, 768, 1536, 80, 160, 320, 640, 1280])
+
+
+def best_length(n):
+    """smallest hand-written line length >= max(2n, 32) (mirror of pruned_best_length)"""
+    return next(L for L in LENGTHS if L >= max(2 * n, 32))
 
 
 # ---------------------------------------------------------------------------- 2D, literal-symbol constructor
@@ -84,9 +91,10 @@ def test_noncubic_3d_pruned(lsfc):
         assert rel_err(lsfc.FFTconvolution(M, b), o.convolve_reduced(G2, b, (n, m, l))) < TOL, pipe
 
 
-@pytest.mark.parametrize("dims", [(24, 20, 18), (48, 16, 30), (17, 33, 19)])
+@pytest.mark.parametrize("dims", [(24, 20, 18), (48, 16, 30), (17, 33, 19), (23, 37, 45), (9, 9, 9)])
 def test_sizes_that_are_not_powers_of_two_3d(lsfc, dims):
-    # any grid size runs in the hand-written pipeline: lines are zero-extended to L/2 = nextpow2(n) in registers
+    # any grid size runs in the hand-written pipeline: lines are zero-extended in registers to half the padded length
+    # L = smallest of 2^k, 3*2^k, 5*2^k that is >= 2n
     n, m, l = dims
     rng = np.random.default_rng(sum(dims))
     G = rng.standard_normal((4 * n, 4 * m, 4 * l)) + 1j * rng.standard_normal((4 * n, 4 * m, 4 * l))
@@ -95,10 +103,11 @@ def test_sizes_that_are_not_powers_of_two_3d(lsfc, dims):
     G2 = o.reduce_symbol(G, (n, m, l))
     ref = o.apply_reduced(G2, nu, 5.0, b, (n, m, l))
     M = lsfc.FastM3D(G, nu, 4 * n, 4 * m, 4 * l, n, m, l, 5.0)
-    np2 = [max(16, 1 << (v - 1).bit_length()) for v in dims]
-    if np.prod(np2) <= 4 * n * m * l:      # embedding costs at most 4x the points: hand-written pipeline
-        assert M.pipeline == "pruned-hip" and M.padded_dims == tuple(2 * v for v in np2)
-    else:                                  # (17, 33, 19): 6.1x -> rocFFT on the exact 2n grid
+    Ls = [best_length(v) for v in dims]
+    if np.prod(Ls) <= 4 * 8 * n * m * l:   # embedding costs at most 4x the points: hand-written pipeline
+        assert M.pipeline == "pruned-hip" and M.padded_dims == tuple(Ls)
+    else:                                  # (9, 9, 9): 32^3 / 18^3 = 5.6x -> rocFFT on the exact 2n grid
+        assert dims == (9, 9, 9)
         assert M.pipeline == "rocfft-reduced" and M.padded_dims == tuple(2 * v for v in dims)
     assert rel_err(M * b, ref) < TOL
     assert rel_err(lsfc.FFTconvolution(M, b), o.convolve_reduced(G2, b, (n, m, l))) < TOL
@@ -113,7 +122,7 @@ def test_reference_example_size_n48_builder(lsfc):
     k = 1.0 / h
     X, Y, Z = o.grid3d(x, x, x)
     M = lsfc.buildFastConvolution3D(x, x, x, X, Y, Z, h, k, o.gaussian_bump)
-    assert M.pipeline == "pruned-hip" and M.padded_dims == (128, 128, 128)
+    assert M.pipeline == "pruned-hip" and M.padded_dims == (96, 96, 96)
     Mo = o.build_fast_convolution3d(x, x, x, X, Y, Z, h, k, o.gaussian_bump)
     b = o.random_vector(n ** 3)
     assert rel_err(M * b, o.mul(Mo, b)) < TOL
@@ -133,9 +142,9 @@ def test_noncubic_2d_pruned(lsfc):
         lsfc.FFTconvolution(M, b)
 
 
-@pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("n", [L // 2 for L in LENGTHS])
 def test_every_line_length_2d(lsfc, n):
-    # one case per hand-written factorisation (padded length 2n = 32 ... 2048), random symbol
+    # one case per hand-written factorisation (padded length 2n = 32 ... 2048: 2^k, 3*2^k, 5*2^k), random symbol
     rng = np.random.default_rng(100 + n)
     G2 = rng.standard_normal((2 * n, 2 * n)) + 1j * rng.standard_normal((2 * n, 2 * n))
     # hand the kernel a literal symbol whose reduction is G2: centred 2n grid (ne == 2n is allowed)
@@ -145,6 +154,41 @@ def test_every_line_length_2d(lsfc, n):
     M = lsfc.FastM(G, nu, 2 * n, 2 * n, n, n, 2.0, quadRule="Greengard_Vico")
     assert M.pipeline == "pruned-hip" and M.padded_dims[:2] == (2 * n, 2 * n)
     assert rel_err(M * b, o.apply_reduced(G2, nu, 2.0, b, (n, n))) < TOL
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+@pytest.mark.parametrize("L", [v for v in LENGTHS if v & (v - 1)])
+def test_every_mixed_radix_line_length_on_every_axis_3d(lsfc, L, axis):
+    # the lines with a factor 3 or 5 in each of the three kinds of pass (contiguous x, strided y, fused z); the other
+    # two axes are short so that the 2n-grid oracle stays small
+    dims = [16, 16, 16]
+    dims[axis] = L // 2
+    n, m, l = dims
+    rng = np.random.default_rng(L + axis)
+    G2 = rng.standard_normal((2 * n, 2 * m, 2 * l)) + 1j * rng.standard_normal((2 * n, 2 * m, 2 * l))
+    nu = rng.uniform(-0.3, 0.3, n * m * l)
+    b = o.random_vector(n * m * l)
+    M = lsfc.FastM3D(np.fft.fftshift(G2), nu, 2 * n, 2 * m, 2 * l, n, m, l, 2.0)
+    assert M.pipeline == "pruned-hip" and M.padded_dims == (2 * n, 2 * m, 2 * l)
+    assert rel_err(M * b, o.apply_reduced(G2, nu, 2.0, b, (n, m, l))) < TOL
+
+
+def test_mixed_radix_even_symbol_3d(lsfc):
+    # an even (Green's-type) symbol on a 3 x 5 x 2^k grid: exercises the y-even / z-even half-symbol storage with the
+    # mixed-radix storage orders (builder on the device vs the slab-wise oracle symbol)
+    n, m, l = 24, 40, 48
+    h = 1.0 / n
+    x, y, z = (-0.5 + h * np.arange(v) for v in (n, m, l))
+    k = 9.0
+    X, Y, Z = o.grid3d(x, y, z)
+    nuv = o.gaussian_bump(X, Y, Z)
+    M = lsfc.buildFastConvolution3D(x, y, z, X, Y, Z, h, k, nuv)
+    assert M.pipeline == "pruned-hip" and M.padded_dims == (48, 80, 96)
+    # (the literal FFTconvolution of the reference allocates zeros(ne, ne, le), src/FastConvolution3D.jl:48, so its
+    # non-cubic form is checked through the reduced-grid identity)
+    G2 = o.reduced_symbol_gv3d(n, m, l, n * h, k, patch_singular=False)
+    b = o.random_vector(n * m * l)
+    assert rel_err(M * b, o.apply_reduced(G2, nuv, k, b, (n, m, l))) < TOL
 
 
 # ---------------------------------------------------------------------------- builders (symbol generated on the device)
