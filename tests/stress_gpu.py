@@ -39,7 +39,7 @@ def main(budget):
         if rng.random() < 0.5:
             sizes = [int(rng.choice([16, 32, 64] if dim == 3 else [16, 32, 64, 128, 256])) for _ in range(dim)]
         else:                                          # arbitrary (odd, non-power-of-two) sizes
-            sizes = [int(rng.integers(9, 49 if dim == 3 else 200)) for _ in range(dim)]
+            sizes = [int(rng.integers(9, 81 if dim == 3 else 400)) for _ in range(dim)]
         N = int(np.prod(sizes))
         lit = tuple(4 * s for s in sizes)
         G = even_symbol(rng, lit) if rng.random() < 0.5 else (rng.standard_normal(lit) + 1j * rng.standard_normal(lit))
