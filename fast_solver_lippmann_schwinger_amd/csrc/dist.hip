@@ -193,16 +193,17 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     LSFC_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
     LSFC_REQUIRE(n % 2 == 0 && m % 2 == 0 && l % 2 == 0, "even grid sizes only");
     LSFC_REQUIRE(l % nranks == 0, "l = %lld is not divisible by the number of ranks %d", (long long)l, nranks);
-    auto np2 = [](int64_t v) { int64_t p2 = 16; while (p2 < v) p2 <<= 1; return p2; };
-    for (int64_t v : { n, m, l }) LSFC_REQUIRE(pruned_length_supported(2 * np2(v)), "distributed plan: grid sizes up to 1024 per axis");
-    LSFC_REQUIRE((2 * np2(n) / 8) % nranks == 0 && is_pow2(nranks), "number of ranks must be a power of two dividing 2*nextpow2(n)/8");
+    for (int64_t v : { n, m, l }) LSFC_REQUIRE(pruned_best_length(v) != 0, "distributed plan: grid sizes up to 1024 per axis");
+    LSFC_REQUIRE(pruned_best_length(l) != 2048, "distributed plan: l up to 768 (the fused z pass needs whole 8-line tiles in LDS)");
+    LSFC_REQUIRE((pruned_best_length(n) / 8) % nranks == 0 && is_pow2(nranks),
+                 "number of ranks must be a power of two dividing Lx/8 (Lx = %d is the padded line length for n = %lld)", pruned_best_length(n), (long long)n);
     std::unique_ptr<lsfc_plan> p(new lsfc_plan());
     const int lz = (int)(l / nranks);
     // local nu: n*m*lz doubles
     plan_common_init(p.get(), 3, n, m, lz, nu_local, omega, LSFC_QUAD_GREENGARD_VICO, flags & ~LSFC_FLAG_LITERAL_PAD, device);
     p->dims[2] = (int)l;                            // dims are global; N stays local
     p->N = n * m * lz;
-    for (int d = 0; d < 3; ++d) { p->pads[d] = 2 * (int)np2(p->dims[d]); p->crop[d] = 0; }
+    for (int d = 0; d < 3; ++d) { p->pads[d] = pruned_best_length(p->dims[d]); p->crop[d] = 0; }
     p->dist.reset(new DistState());
     DistState* d = p->dist.get();
     d->rank = rank; d->nranks = nranks; d->sim = sim; d->lz = lz; d->W = p->pads[0] / nranks;

@@ -42,7 +42,7 @@ static constexpr int XB = 8;           // x' lines per strided workgroup: 8 * 16
 template <class C, int LPW, bool SPLIT, bool EXACT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __restrict__ out,
-            const cplx* __restrict__ tw, int64_t nlines, int logW, int wmask, int Wp, int n, int64_t bstride) {
+            const cplx* __restrict__ tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -63,13 +63,14 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
     fft_forward<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
     if (valid) {
-        // storage index s of this line goes to chunk s>>logW (one chunk per destination rank of the slab
-        // transpose; a single chunk of width L on one GPU: logW = 31, wmask = all ones): out[chunk][line][s & wmask],
-        // row pitch Wp >= W
+        // storage index s of this line goes to chunk s / W (one chunk per destination rank and pipeline stage of the
+        // slab transpose; a single chunk of width L on one GPU): out[chunk][line][s % W], row pitch Wp >= W.  The
+        // division is exact by multiplication: wmagic = floor(2^22 / W) + 1, valid for s < 2048.
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int s = t + T * e;
-            out[(int64_t)(s >> logW) * bstride + line * Wp + (s & wmask)] = v[e];
+            const int c = (int)(((unsigned)s * (unsigned)wmagic) >> 22);
+            out[(int64_t)c * bstride + line * Wp + (s - c * W)] = v[e];
         }
     }
 }
@@ -77,7 +78,7 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
 template <class C, int LPW, bool SPLIT, bool EXACT>
 __global__ __launch_bounds__(C::T * LPW)
 void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alpha, double beta,
-            const cplx* __restrict__ tw, int64_t nlines, int logW, int wmask, int Wp, int n, int64_t bstride) {
+            const cplx* __restrict__ tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride) {
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -89,7 +90,8 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int s = t + T * e;
-        v[e] = in[(int64_t)(s >> logW) * bstride + lc * Wp + (s & wmask)];
+        const int c = (int)(((unsigned)s * (unsigned)wmagic) >> 22);
+        v[e] = in[(int64_t)c * bstride + lc * Wp + (s - c * W)];
     }
     fft_inverse<C, LL, true>(v, t, tw, smem, ll * LL::line_elems(C::L), 0);
     if (valid) {
@@ -279,21 +281,21 @@ template <class C> struct Tune {
     static constexpr int LINES = (C::T * XB <= 512 || (C::E <= 8 && C::T * XB <= 1024)) ? XB : 512 / C::T;
 };
 
-template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int logW, int wmask, int Wp, int n, int64_t bstride, hipStream_t st) {
+template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = (n == C::L / 2) ? k_xfwd<C, LPW, SPLIT, true> : k_xfwd<C, LPW, SPLIT, false>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, logW, wmask, Wp, n, bstride);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, wmagic, W, Wp, n, bstride);
 }
-template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int logW, int wmask, int Wp, int n, int64_t bstride, hipStream_t st) {
+template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = (n == C::L / 2) ? k_xinv<C, LPW, SPLIT, true> : k_xinv<C, LPW, SPLIT, false>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, logW, wmask, Wp, n, bstride);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, wmagic, W, Wp, n, bstride);
 }
 static void ytile(const PrunedTuning& tn, int L, int ngrp, int l, int& TG, int& TZ) {
     // auto (0): all groups x 1 plane, except at L >= 1024 where 32 groups x 8 planes keeps the 128-B chunks that the
@@ -400,26 +402,24 @@ void FAM(pruned_perm)(int L, int* freq_of_storage) {
     LSFC_DISPATCH_L(L, perm_table<C>(freq_of_storage));
 }
 
-// chunk addressing of the x passes: power-of-two chunk widths by shift and mask; a single chunk (W = L) of any length
-static void chunk_bits(int L, int W, int& logW, int& wmask) {
-    if (W == L) { logW = 31; wmask = 0x7fffffff; return; }
-    int l = 0; while ((1 << l) < W) ++l;
-    LSFC_REQUIRE((1 << l) == W, "chunk width %d is not a power of two", W);
-    logW = l; wmask = W - 1;
+// chunk addressing of the x passes: s / W by multiplication with wmagic = floor(2^22 / W) + 1 (exact for s < 2048:
+// s * (wmagic * W - 2^22) <= s * W < 2^22; the product s * wmagic stays below 2^32 for W >= 2)
+static int chunk_magic(int L, int W) {
+    LSFC_REQUIRE(W >= 8 && W <= L && L % W == 0 && L <= 2048, "chunk width %d does not divide the line length %d", W, L);
+    return (1 << 22) / W + 1;
 }
-
 void FAM(pruned_xfwd)(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
-    int logW, wmask; chunk_bits(L, W, logW, wmask);
+    const int wmagic = chunk_magic(L, W);
     if (bstride <= 0) bstride = (int64_t)Wp * nlines;       // dense chunks: [chunk][line][Wp]
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, logW, wmask, Wp, n, bstride, st))); }
-    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, logW, wmask, Wp, n, bstride, st))); }
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
+    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
     LSFC_HIP(hipGetLastError());
 }
 void FAM(pruned_xinv)(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
-    int logW, wmask; chunk_bits(L, W, logW, wmask);
+    const int wmagic = chunk_magic(L, W);
     if (bstride <= 0) bstride = (int64_t)Wp * nlines;       // dense chunks: [chunk][line][Wp]
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, logW, wmask, Wp, n, bstride, st))); }
-    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, logW, wmask, Wp, n, bstride, st))); }
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
+    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
     LSFC_HIP(hipGetLastError());
 }
 void FAM(pruned_yfwd)(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {

@@ -89,9 +89,12 @@ def test_distributed_plan_single_rank_production_path(lsfc, chunks, monkeypatch)
     assert hist.isconverged and np.linalg.norm(o.mul(Mo, u) - rhs) / np.linalg.norm(rhs) < 1e-7
 
 
-def test_simulated_ranks_grid_sizes_not_powers_of_two(lsfc):
-    # slab decomposition of a 24 x 20 x 18 grid (working grid 64 x 64 x 64): only l must divide by the rank count
-    n, m, l, k = 24, 20, 18, 7.0
+@pytest.mark.parametrize("shape,ranks", [((24, 20, 18), (1, 2)), ((48, 40, 96), (2, 4)), ((80, 24, 64), (4,))])
+def test_simulated_ranks_grid_sizes_not_powers_of_two(lsfc, shape, ranks):
+    # slab decomposition on mixed-radix working grids (24 x 20 x 18 -> 48^3, 48 x 40 x 96 -> 96 x 80 x 192,
+    # 80 x 24 x 64 -> 160 x 48 x 128): the rank count must divide l and Lx/8; chunk widths need not be powers of two
+    n, m, l = shape
+    k = 7.0
     h = 1.0 / n
     rng = np.random.default_rng(12)
     nu = rng.uniform(-0.3, 0.3, n * m * l)
@@ -99,7 +102,7 @@ def test_simulated_ranks_grid_sizes_not_powers_of_two(lsfc):
     x = -0.5 + h * np.arange(n)
     M = lsfc.buildFastConvolution3D(x, x[:1].repeat(m), x[:1].repeat(l), None, None, None, h, k, nu)
     ref = M * b
-    for nranks in (1, 2):
+    for nranks in ranks:
         S = SimulatedRanks(n, m, l, h, k, nu, nranks)
         assert rel_err(S.apply(b), ref) < 1e-13
         S.close()
