@@ -351,7 +351,7 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     }
 }
 
-// half-tile z pass (L = 1024 in 3D tiled layout only): 4-line workgroups, sibling halves 8 blocks apart
+// half-tile z pass (L = 1024 and L = 1536 in the 3D tiled layout only): 4-line workgroups, sibling halves 8 blocks apart
 template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static void zfused_half_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                                                          int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
                                                          const int2* ytab, const int* zm, int nin, hipStream_t st) {
@@ -463,6 +463,26 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
         case 2: LSFC_ZH(true, true, 2); break;
         case 3: LSFC_ZH(true, false, 3); break;
         default: LSFC_ZH(false, false, 2); break;
+        }
+#undef LSFC_ZH
+        LSFC_HIP(hipGetLastError());
+        return;
+    }
+#elif LSFC_FAMILY == 3
+    // the 1536-point line holds 24 elements per thread: in 8-line (512-thread) workgroups the fused pass is capped at
+    // 256 registers and spills.  Half tiles (4 lines, 256 threads, one wave per SIMD) lift the cap.
+    // z_half: 0 off, 1 (auto) whole-complex exchange + prefetch, 2 split + prefetch, 3 split, 4 whole-complex
+    // (768^3: fused pass 36.7 -> 29.7 ms, apply 64.7 -> 57.4 ms)
+    const int zh = tn.z_half >= 0 ? tn.z_half : 1;
+    if (L == 1536 && zh > 0 && dLine == 8 && ((int64_t)(Lx / XB) * nouter) % 8 == 0) {
+        using C = Cfg1536;
+#define LSFC_ZH(SP, PF) do { if (zm) zfused_half_t<C, SP, PF, 1, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st); \
+                             else zfused_half_t<C, SP, PF, 1, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st); } while (0)
+        switch (zh) {
+        case 1: LSFC_ZH(false, true); break;
+        case 2: LSFC_ZH(true, true); break;
+        case 3: LSFC_ZH(true, false); break;
+        default: LSFC_ZH(false, false); break;
         }
 #undef LSFC_ZH
         LSFC_HIP(hipGetLastError());
