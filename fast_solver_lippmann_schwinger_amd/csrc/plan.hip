@@ -359,6 +359,8 @@ lsfc_plan::~lsfc_plan() {}
 extern "C" {
 
 const char* lsfc_last_error(void) { return g_last_error; }
+int lsfc_padded_length(int64_t n) { return (n >= 1 && n <= 1024) ? lsfc::pruned_best_length(n) : 0; }
+
 const char* lsfc_version(void) { return "lsfc 0.1 (gfx950, rocFFT + hand-written pruned FFT passes)"; }
 
 static int create_from_literal(lsfc_plan** out, int ndim, int64_t n, int64_t m, int64_t l, int64_t ne, int64_t me, int64_t le,

@@ -224,6 +224,11 @@ int lsfc_dist_sim_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_
                                    const double* nu_local, unsigned flags, int device, int rank, int nranks);
 int lsfc_dist_sim_apply(lsfc_plan** plans, int nranks, const double* const* x, double* const* y, int mode);
 
+/* Padded line length the hand-written pipeline uses for an axis of n grid points: the smallest of 2^k, 3*2^k, 5*2^k
+ * (32 ... 2048) that is >= 2n; 0 if there is none (such axes run through rocFFT on the exact 2n grid).  Pure host
+ * arithmetic, no device needed.  (The reference pads every axis to 4n, src/FastConvolution3D.jl:48.) */
+int lsfc_padded_length(int64_t n);
+
 /* ---- errors ---------------------------------------------------------------- */
 const char* lsfc_last_error(void);
 const char* lsfc_version(void);

@@ -28,6 +28,20 @@ def test_library_exports_every_declared_symbol():
     assert sorted(L.SIGNATURES) == names, "python binding and header disagree"
 
 
+def test_padded_length_rule():
+    # host arithmetic only: smallest of 2^k, 3*2^k, 5*2^k in [32, 2048] that is >= 2n
+    import fast_solver_lippmann_schwinger_amd._lib as L
+    lib = L.load()
+    lengths = sorted({v for k in range(12) for v in (2 ** k, 3 * 2 ** k, 5 * 2 ** k)
+                      if (v >= 32 and v <= 2048) and not (v % 3 == 0 and v < 48) and not (v % 5 == 0 and v < 80)})
+    assert lengths == [32, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 2048]
+    for n in range(1, 1025):
+        assert lib.lsfc_padded_length(n) == next(v for v in lengths if v >= max(2 * n, 32)), n
+    assert lib.lsfc_padded_length(0) == 0 and lib.lsfc_padded_length(1025) == 0
+    # from n = 24 on an axis is never padded by more than 4/3 beyond 2n (3*2^k -> 2^(k+2) is the widest gap)
+    assert max(lib.lsfc_padded_length(n) / (2 * n) for n in range(24, 1025)) < 4 / 3
+
+
 def test_header_compiles_as_c():
     src = '#include "lsfc.h"\nint main(void){ lsfc_gmres_opts o; (void)o; return LSFC_OK; }\n'
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"],
