@@ -194,7 +194,6 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     LSFC_REQUIRE(n % 2 == 0 && m % 2 == 0 && l % 2 == 0, "even grid sizes only");
     LSFC_REQUIRE(l % nranks == 0, "l = %lld is not divisible by the number of ranks %d", (long long)l, nranks);
     for (int64_t v : { n, m, l }) LSFC_REQUIRE(pruned_best_length(v) != 0, "distributed plan: grid sizes up to 1024 per axis");
-    LSFC_REQUIRE(pruned_best_length(l) != 2048, "distributed plan: l up to 768 (the fused z pass needs whole 8-line tiles in LDS)");
     LSFC_REQUIRE((pruned_best_length(n) / 8) % nranks == 0 && is_pow2(nranks),
                  "number of ranks must be a power of two dividing Lx/8 (Lx = %d is the padded line length for n = %lld)", pruned_best_length(n), (long long)n);
     std::unique_ptr<lsfc_plan> p(new lsfc_plan());

@@ -468,6 +468,15 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
         LSFC_HIP(hipGetLastError());
         return;
     }
+    // the 2048-point line in the 3D tiled layout: a whole 8-line tile does not fit the 160 KiB of LDS, half tiles do
+    if (L == 2048 && dLine == 8) {
+        LSFC_REQUIRE(((int64_t)(Lx / XB) * nouter) % 8 == 0, "half-tile z pass needs a multiple of 8 tiles");
+        using C = Cfg2048;
+        if (zm) zfused_half_t<C, false, false, 2, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
+        else zfused_half_t<C, false, false, 2, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
+        LSFC_HIP(hipGetLastError());
+        return;
+    }
 #elif LSFC_FAMILY == 3
     // the 1536-point line holds 24 elements per thread: in 8-line (512-thread) workgroups the fused pass is capped at
     // 256 registers and spills.  Half tiles (4 lines, 256 threads, one wave per SIMD) lift the cap.

@@ -120,7 +120,6 @@ static bool pruned_eligible(const lsfc_plan* p) {
     for (int d = 0; d < p->ndim; ++d) {
         const int L = pruned_best_length(p->dims[d]);
         if (L == 0) return false;
-        if (p->ndim == 3 && d == 2 && L == 2048) return false;     // the fused z pass needs whole 8-line tiles in LDS
         ratio *= (double)L / (2.0 * (double)p->dims[d]);
     }
     return ratio <= 4.0;

@@ -169,8 +169,8 @@ def test_every_mixed_radix_line_length_on_every_axis_3d(lsfc, L, axis):
     nu = rng.uniform(-0.3, 0.3, n * m * l)
     b = o.random_vector(n * m * l)
     M = lsfc.FastM3D(np.fft.fftshift(G2), nu, 2 * n, 2 * m, 2 * l, n, m, l, 2.0)
-    # (the longest line, 2048, fits the fused z pass only in the 2D layout: a 3D grid with l = 1024 takes rocFFT)
-    assert M.pipeline == ("rocfft-reduced" if (L == 2048 and axis == 2) else "pruned-hip")
+    # (the longest line, 2048, runs the fused z pass of the 3D layout in 4-line half tiles)
+    assert M.pipeline == "pruned-hip"
     assert M.padded_dims == (2 * n, 2 * m, 2 * l)
     assert rel_err(M * b, o.apply_reduced(G2, nu, 2.0, b, (n, m, l))) < TOL
 
