@@ -56,15 +56,17 @@ def main(budget):
                 M = ls.FastM(G, nu, *lit, *sizes, k, quadRule="Greengard_Vico", flags=flags)
             errs[name] = rel(M * b, ref)
             M.close()
-        pow2 = all(v & (v - 1) == 0 for v in sizes)
-        if dim == 3 and pow2:
+        even = all(v % 2 == 0 for v in sizes)
+        Lx8 = ls._lib.load().lsfc_padded_length(sizes[0]) // 8
+        ranks = [p for p in (1, 2, 4, 8) if sizes[-1] % p == 0 and Lx8 % p == 0]
+        if dim == 3 and even and ranks:
             # builder + simulated ranks against the single-GPU builder (same generated symbol)
             n, m, l = sizes
             h = 1.0 / n
             x = -0.5 + h * np.arange(n)
             Mb = ls.buildFastConvolution3D(x, x[:1].repeat(m), x[:1].repeat(l), None, None, None, h, k, nu)
             yb = Mb * b
-            P = int(rng.choice([p for p in (1, 2, 4, 8) if l % p == 0 and (2 * n // 8) % p == 0]))
+            P = int(rng.choice(ranks))
             S = SimulatedRanks(n, m, l, h, k, nu, P)
             errs[f"sim{P}"] = rel(S.apply(b), yb)
             S.close(); Mb.close()
