@@ -1,7 +1,9 @@
 // Shared host-side helpers for the lsfc HIP library (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstdint>
 #include <string>
@@ -41,6 +43,19 @@ template <class F> int guarded(F&& body) {
     catch (const std::exception& e) { set_last_error("%s", e.what()); return LSFC_EHIP; }
     catch (...) { set_last_error("unknown error"); return LSFC_EHIP; }
 }
+
+// LSFC_PLAN_TIMING=1: wall-clock phases of plan creation on stderr (the device is synchronised at every mark)
+struct PhaseTimer {
+    bool on; std::chrono::steady_clock::time_point t0;
+    PhaseTimer() : on(getenv("LSFC_PLAN_TIMING") && getenv("LSFC_PLAN_TIMING")[0] == '1'), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[lsfc plan] %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 

@@ -404,12 +404,16 @@ int lsfc_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, doub
         LSFC_REQUIRE(out, "NULL argument"); *out = nullptr;
         LSFC_REQUIRE(n % 2 == 0 && m % 2 == 0 && l % 2 == 0, "buildFastConvolution3D: even n only (the reference's odd branch is broken)");
         LSFC_REQUIRE(box > 0, "box must be positive");
+        PhaseTimer pt;
         std::unique_ptr<lsfc_plan> p(new lsfc_plan());
         plan_common_init(p.get(), 3, n, m, l, nu, omega, LSFC_QUAD_GREENGARD_VICO, flags & ~LSFC_FLAG_LITERAL_PAD, device);
+        pt.mark("init + nu upload");
         DevBuf<cplx> G2;
         plan_choose_reduced_grid(p.get());
         symbol_gv3d_reduced(p.get(), box, G2);
+        pt.mark("symbol (total)");
         plan_finish_from_reduced(p.get(), G2);
+        pt.mark("tables, symbol permutation, work arrays");
         *out = p.release();
     });
 }

@@ -83,15 +83,18 @@ void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2) {
     const int patch = (p->flags & LSFC_FLAG_PATCH_SINGULAR) ? 1 : 0;
     hipStream_t st = p->stream;
 
+    PhaseTimer pt;
     const int64_t plane_lit = (int64_t)P0 * P1, plane_red = (int64_t)Q0 * Q1;
     // chunk of z-frequency planes: ~1 GiB of literal planes at a time
     int C = (int)std::max<int64_t>(1, std::min<int64_t>(P2, ((int64_t)1 << 30) / (plane_lit * (int64_t)sizeof(cplx))));
     while (P2 % C) --C;
     DevBuf<cplx> U; U.alloc((size_t)(plane_red * P2));
+    pt.mark("symbol: alloc U");
     {
         DevBuf<cplx> W; W.alloc((size_t)(plane_lit * C));
         const size_t len2[2] = { (size_t)P0, (size_t)P1 };
         RocFft inv2d; inv2d.create(2, len2, false, (size_t)C);
+        pt.mark("symbol: alloc W + rocFFT 2D plan");
         for (int z0 = 0; z0 < P2; z0 += C) {
             hipLaunchKernelGGL(k_gen_gv3d_planes, dim3(grid_for(plane_lit * C)), dim3(256), 0, st, W.p, P0, P1, P2, z0, C, dk, L, k, eiLk, patch, limit);
             inv2d.exec(W.p, st);
@@ -99,22 +102,35 @@ void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2) {
         }
         LSFC_HIP(hipGetLastError());
         LSFC_HIP(hipStreamSynchronize(st));
+        pt.mark("symbol: planes (gen, ifft2, crop)");
     }
+    pt.mark("symbol: free W + 2D plan");
     {
         RocFft invz; invz.create_strided_1d((size_t)P2, (size_t)plane_red, 1, (size_t)plane_red, false);
+        pt.mark("symbol: rocFFT z plan");
         invz.exec(U.p, st);
         LSFC_HIP(hipStreamSynchronize(st));
+        pt.mark("symbol: ifft z");
     }
+    pt.mark("symbol: free z plan");
     G2.alloc((size_t)(plane_red * Q2));
+    pt.mark("symbol: alloc G2");
     hipLaunchKernelGGL(k_crop_z, dim3(grid_for(plane_red * Q2)), dim3(256), 0, st, U.p, G2.p, plane_red, P2, Q2,
                        1.0 / ((double)P0 * (double)P1 * (double)P2));
     LSFC_HIP(hipGetLastError());
     LSFC_HIP(hipStreamSynchronize(st));
+    pt.mark("symbol: crop z");
     U.release();
+    pt.mark("symbol: free U");
     const size_t len3[3] = { (size_t)Q0, (size_t)Q1, (size_t)Q2 };
-    RocFft fwd; fwd.create(3, len3, true);
-    fwd.exec(G2.p, st);
-    LSFC_HIP(hipStreamSynchronize(st));
+    {
+        RocFft fwd; fwd.create(3, len3, true);
+        pt.mark("symbol: rocFFT 3D plan");
+        fwd.exec(G2.p, st);
+        LSFC_HIP(hipStreamSynchronize(st));
+        pt.mark("symbol: fft 3D");
+    }
+    pt.mark("symbol: free 3D plan");
 }
 
 // ---- Gtruncated2D (src/Functions.jl:40-42), centred literal (4n x 4m) ---------
