@@ -27,9 +27,11 @@ void rocfft_global_setup() {
     std::call_once(once, [] { rocfft_setup(); });
 }
 
-RocFft::~RocFft() {
-    if (info) rocfft_execution_info_destroy(info);
-    if (plan) rocfft_plan_destroy(plan);
+RocFft::~RocFft() { release(); }
+void RocFft::release() {
+    if (info) { rocfft_execution_info_destroy(info); info = nullptr; }
+    if (plan) { rocfft_plan_destroy(plan); plan = nullptr; }
+    work.release();
 }
 void RocFft::finish_create() {
     size_t wsz = 0;
@@ -37,7 +39,7 @@ void RocFft::finish_create() {
     LSFC_ROCFFT(rocfft_execution_info_create(&info));
     if (wsz) { work.alloc(wsz); LSFC_ROCFFT(rocfft_execution_info_set_work_buffer(info, work.p, wsz)); }
 }
-void RocFft::create(int ndim, const size_t* lengths, bool forward, size_t batch) {
+void RocFft::create(int ndim, const size_t* lengths, bool forward, size_t batch, bool lazy_work) {
     rocfft_global_setup();
     // drop unit dimensions
     size_t len[3]; int nd = 0;
@@ -46,9 +48,9 @@ void RocFft::create(int ndim, const size_t* lengths, bool forward, size_t batch)
     LSFC_ROCFFT(rocfft_plan_create(&plan, rocfft_placement_inplace,
                                    forward ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
                                    rocfft_precision_double, nd, len, batch, nullptr));
-    finish_create();
+    if (!lazy_work) finish_create();
 }
-void RocFft::create_strided_1d(size_t length, size_t stride, size_t dist, size_t batch, bool forward) {
+void RocFft::create_strided_1d(size_t length, size_t stride, size_t dist, size_t batch, bool forward, bool lazy_work) {
     rocfft_global_setup();
     rocfft_plan_description desc = nullptr;
     LSFC_ROCFFT(rocfft_plan_description_create(&desc));
@@ -61,9 +63,10 @@ void RocFft::create_strided_1d(size_t length, size_t stride, size_t dist, size_t
                                rocfft_precision_double, 1, &length, batch, desc);
     rocfft_plan_description_destroy(desc);
     LSFC_ROCFFT(s);
-    finish_create();
+    if (!lazy_work) finish_create();
 }
 void RocFft::exec(void* buf, hipStream_t stream) {
+    if (!info) finish_create();
     LSFC_ROCFFT(rocfft_execution_info_set_stream(info, stream));
     void* in[1] = { buf };
     LSFC_ROCFFT(rocfft_execute(plan, in, nullptr, info));

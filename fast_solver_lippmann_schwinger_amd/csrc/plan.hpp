@@ -17,11 +17,14 @@ struct RocFft {
     RocFft() = default;
     RocFft(const RocFft&) = delete; RocFft& operator=(const RocFft&) = delete;
     ~RocFft();
-    // dense ndim-dimensional transform (lengths fastest first), `batch` contiguous copies
-    void create(int ndim, const size_t* lengths, bool forward, size_t batch = 1);
+    // dense ndim-dimensional transform (lengths fastest first), `batch` contiguous copies.
+    // lazy_work: the work buffer is allocated at the first exec() instead of here (plans created ahead of their use,
+    // e.g. concurrently on helper threads while rocFFT compiles their kernels, should not hold tens of GB meanwhile)
+    void create(int ndim, const size_t* lengths, bool forward, size_t batch = 1, bool lazy_work = false);
     // 1D transforms of `length` with element stride `stride`, `batch` lines `dist` apart
-    void create_strided_1d(size_t length, size_t stride, size_t dist, size_t batch, bool forward);
+    void create_strided_1d(size_t length, size_t stride, size_t dist, size_t batch, bool forward, bool lazy_work = false);
     void exec(void* buf, hipStream_t stream);
+    void release();            // plan, execution info and work buffer
 private:
     void finish_create();
 };

@@ -1,6 +1,7 @@
 // Symbol generators: the builder side of the reference (buildFastConvolution*,
 // Gtruncated2D/3D, buildGConv) evaluated on the device (gfx950), setup-time only.
 #include "plan.hpp"
+#include <future>
 #include "pointwise.hpp"
 #include <cmath>
 
@@ -88,12 +89,25 @@ void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2) {
     // chunk of z-frequency planes: ~1 GiB of literal planes at a time
     int C = (int)std::max<int64_t>(1, std::min<int64_t>(P2, ((int64_t)1 << 30) / (plane_lit * (int64_t)sizeof(cplx))));
     while (P2 % C) --C;
+    // rocFFT compiles the kernels of a new transform shape at plan creation (0.3-0.8 s each in a fresh process): the
+    // three plans are created concurrently on helper threads, and the two needed later keep compiling while the
+    // planes are evaluated
+    const int dev = p->device;
+    RocFft inv2d, invz, fwd;
+    const size_t len2[2] = { (size_t)P0, (size_t)P1 };
+    const size_t len3[3] = { (size_t)Q0, (size_t)Q1, (size_t)Q2 };
+    auto on_device = [dev](auto&& body) { return std::async(std::launch::async, [dev, body] { LSFC_HIP(hipSetDevice(dev)); body(); }); };
+    auto f2d = on_device([&inv2d, &len2, C] { inv2d.create(2, len2, false, (size_t)C, true); });
+    auto fz = on_device([&invz, P2, plane_red] { invz.create_strided_1d((size_t)P2, (size_t)plane_red, 1, (size_t)plane_red, false, true); });
+    auto f3d = on_device([&fwd, &len3] { fwd.create(3, len3, true, 1, true); });
+    // (a failure below must not unwind while a helper still references the plans)
+    struct Joiner { std::future<void>* f[3]; ~Joiner() { for (auto* x : f) if (x->valid()) x->wait(); } } joiner{{ &f2d, &fz, &f3d }};
+
     DevBuf<cplx> U; U.alloc((size_t)(plane_red * P2));
     pt.mark("symbol: alloc U");
     {
         DevBuf<cplx> W; W.alloc((size_t)(plane_lit * C));
-        const size_t len2[2] = { (size_t)P0, (size_t)P1 };
-        RocFft inv2d; inv2d.create(2, len2, false, (size_t)C);
+        f2d.get();
         pt.mark("symbol: alloc W + rocFFT 2D plan");
         for (int z0 = 0; z0 < P2; z0 += C) {
             hipLaunchKernelGGL(k_gen_gv3d_planes, dim3(grid_for(plane_lit * C)), dim3(256), 0, st, W.p, P0, P1, P2, z0, C, dk, L, k, eiLk, patch, limit);
@@ -103,15 +117,15 @@ void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2) {
         LSFC_HIP(hipGetLastError());
         LSFC_HIP(hipStreamSynchronize(st));
         pt.mark("symbol: planes (gen, ifft2, crop)");
+        inv2d.release();
     }
     pt.mark("symbol: free W + 2D plan");
-    {
-        RocFft invz; invz.create_strided_1d((size_t)P2, (size_t)plane_red, 1, (size_t)plane_red, false);
-        pt.mark("symbol: rocFFT z plan");
-        invz.exec(U.p, st);
-        LSFC_HIP(hipStreamSynchronize(st));
-        pt.mark("symbol: ifft z");
-    }
+    fz.get();
+    pt.mark("symbol: rocFFT z plan");
+    invz.exec(U.p, st);
+    LSFC_HIP(hipStreamSynchronize(st));
+    pt.mark("symbol: ifft z");
+    invz.release();
     pt.mark("symbol: free z plan");
     G2.alloc((size_t)(plane_red * Q2));
     pt.mark("symbol: alloc G2");
@@ -122,14 +136,12 @@ void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2) {
     pt.mark("symbol: crop z");
     U.release();
     pt.mark("symbol: free U");
-    const size_t len3[3] = { (size_t)Q0, (size_t)Q1, (size_t)Q2 };
-    {
-        RocFft fwd; fwd.create(3, len3, true);
-        pt.mark("symbol: rocFFT 3D plan");
-        fwd.exec(G2.p, st);
-        LSFC_HIP(hipStreamSynchronize(st));
-        pt.mark("symbol: fft 3D");
-    }
+    f3d.get();
+    pt.mark("symbol: rocFFT 3D plan");
+    fwd.exec(G2.p, st);
+    LSFC_HIP(hipStreamSynchronize(st));
+    pt.mark("symbol: fft 3D");
+    fwd.release();
     pt.mark("symbol: free 3D plan");
 }
 
