@@ -504,7 +504,9 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
     // (z pass -15..-30 %), whole-complex exchanges on the factor-3 lines from L = 384; the 1536-point line (24
     // elements per thread in 512-thread workgroups) has no registers left for the prefetch
 #if LSFC_FAMILY == 2
-    const bool e16 = L >= 1024, full = e16;
+    // (the 2048-point line reaches this point only in the 2D layout, 4 lines per workgroup: no prefetch there,
+    // fused pass 54 -> 46 us at 2D n = 1024)
+    const bool e16 = L == 1024, full = L >= 1024;
 #elif LSFC_FAMILY == 3
     const bool e16 = L >= 384 && L < 1536, full = L >= 384;
 #else
