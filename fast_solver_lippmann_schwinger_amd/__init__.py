@@ -4,9 +4,10 @@ behind the reference's own operator surface.  See DESIGN.md and include/lsfc.h."
 from .operators import (FastM, FastM3D, ConvergenceHistory, FFTconvolution, buildFastConvolution,
                         buildFastConvolution3D, eltype, fastconvolution, gmres_, mul_, profile_apply,
                         referenceValsTrapRule, sampleG3D, sampleGConv, size, time_apply)
+from .preconditioner import SparsifyingPreconditioner
 from ._lib import LsfcError, device_count, load
 
 __all__ = ["FastM", "FastM3D", "ConvergenceHistory", "FFTconvolution", "buildFastConvolution",
            "buildFastConvolution3D", "eltype", "fastconvolution", "gmres_", "mul_", "profile_apply",
            "referenceValsTrapRule", "sampleG3D", "sampleGConv", "size", "time_apply", "LsfcError",
-           "device_count", "load"]
+           "device_count", "load", "SparsifyingPreconditioner"]

@@ -1,0 +1,344 @@
+// Device-resident apply of the reference's SparsifyingPreconditioner (src/preconditioner.jl:27-58, 132-170):
+//
+//     v  <-  Msp^{-1} (As v)
+//
+// As is a sparse matrix (SpMV), Msp^{-1} is applied through the LU factors the caller computed on the host (UMFPACK
+// `lu(Msp)` in the reference, src/preconditioner.jl:35): (Rs .* Msp)[p, q] = L U.  The factorisation itself, and the
+// assembly of As / Msp, stay on the host and out of scope; what moves to the device is the part that runs once per
+// Arnoldi step, so the Krylov vector no longer crosses PCIe twice per step.
+//
+// Sparse triangular solves by level scheduling: rows are grouped by dependency depth; a wide level is one launch
+// over all its rows, a run of narrow levels (the long tail of an LU factor: the dense trailing separator block is
+// one row per level) is ONE single-workgroup launch that walks the levels with barriers.  The whole sequence
+// SpMV -> L solve -> U solve -> scatter is captured once in a hipGraph on fixed internal buffers and replayed per
+// apply: one graph launch instead of hundreds of kernel launches.
+#include "common.hpp"
+#include <algorithm>
+#include <complex>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+namespace lsfc {
+
+// ---- kernels -------------------------------------------------------------------------------------------------------
+
+// y[k] = scale[row] * sum_j A[row, j] x[j],  row = gather[k]   (CSR, LPR lanes per row)
+template <int LPR>
+__global__ void k_spmv_gather(const int64_t* __restrict__ rowptr, const int* __restrict__ col, const cplx* __restrict__ val,
+                              const int* __restrict__ gather, const double* __restrict__ scale, const cplx* __restrict__ x,
+                              cplx* __restrict__ y, int nrows) {
+    const int g = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / LPR), lane = threadIdx.x % LPR;
+    if (g >= nrows) return;                       // (whole LPR-groups leave together: blockDim is a multiple of LPR)
+    const int row = gather ? gather[g] : g;
+    double sx = 0.0, sy = 0.0;
+    for (int64_t e = rowptr[row] + lane; e < rowptr[row + 1]; e += LPR) {
+        const cplx a = val[e], b = x[col[e]];
+        sx += a.x * b.x - a.y * b.y; sy += a.x * b.y + a.y * b.x;
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, LPR); sy += __shfl_xor(sy, o, LPR); }
+    if (lane == 0) { const double s = scale ? scale[row] : 1.0; y[g] = make_double2(s * sx, s * sy); }
+}
+
+// one row of a triangular solve, LANES lanes: x[row] = (b[row] - sum_{j != row} a_j x[col_j]) * inv_diag
+// (rows are stored in level order: entry k of the sorted arrays is original row rowid[k]; off-diagonal entries only)
+template <int LANES>
+__device__ __forceinline__ void trsv_row(int k, int lane, const int64_t* __restrict__ rowptr, const int* __restrict__ col,
+                                         const cplx* __restrict__ val, const int* __restrict__ rowid, const cplx* __restrict__ invd,
+                                         const cplx* __restrict__ b, cplx* x) {
+    double sx = 0.0, sy = 0.0;
+    for (int64_t e = rowptr[k] + lane; e < rowptr[k + 1]; e += LANES) {
+        const cplx a = val[e], v = x[col[e]];
+        sx += a.x * v.x - a.y * v.y; sy += a.x * v.y + a.y * v.x;
+    }
+#pragma unroll
+    for (int o = LANES / 2; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, LANES); sy += __shfl_xor(sy, o, LANES); }
+    if (lane == 0) {
+        const int row = rowid[k];
+        const cplx r = make_double2(b[row].x - sx, b[row].y - sy), d = invd[k];
+        x[row] = make_double2(r.x * d.x - r.y * d.y, r.x * d.y + r.y * d.x);
+    }
+}
+
+// one wide level: rows [first, first + nrows) of the sorted order, 8 lanes per row
+__global__ void k_trsv_level(int first, int nrows, const int64_t* __restrict__ rowptr, const int* __restrict__ col, const cplx* __restrict__ val,
+                             const int* __restrict__ rowid, const cplx* __restrict__ invd, const cplx* __restrict__ b, cplx* x) {
+    const int g = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / 8), lane = threadIdx.x % 8;
+    if (g >= nrows) return;
+    trsv_row<8>(first + g, lane, rowptr, col, val, rowid, invd, b, x);
+}
+
+// a run of narrow levels [l0, l1) in ONE workgroup of 1024 threads: level after level, a barrier in between.
+// Every level of the run has at most 128 rows.  The tail of a sparse LU factor is deep and thin -- at 2D 257 x 257 a
+// third of the fill sits in 1391 levels of ONE row with ~740 entries each -- so the lanes are dealt out per level:
+// 1024 / (rows rounded up to a power of two) lanes per row, all 1024 on a single row; sums are folded by wave
+// shuffles and, beyond one wave per row, through LDS.  The critical path of a level is then one dependent pair of
+// loads (col -> x[col]) and a reduction, not a loop over the row.
+__global__ __launch_bounds__(1024)
+void k_trsv_chain(int l0, int l1, const int* __restrict__ lvlptr, const int64_t* __restrict__ rowptr, const int* __restrict__ col,
+                  const cplx* __restrict__ val, const int* __restrict__ rowid, const cplx* __restrict__ invd, const cplx* __restrict__ b, cplx* x) {
+    __shared__ double psx[16], psy[16];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    for (int l = l0; l < l1; ++l) {
+        const int first = lvlptr[l], nrows = lvlptr[l + 1] - first;       // uniform over the workgroup
+        int p2 = 1; while (p2 < nrows) p2 <<= 1;
+        const int lanes = 1024 / p2;                                       // 8 ... 1024, a power of two
+        const int g = tid / lanes, lane = tid % lanes;
+        const bool active = g < nrows;
+        const int k = first + (active ? g : 0);
+        double sx = 0.0, sy = 0.0;
+        if (active) {
+            const int64_t e1 = rowptr[k + 1];
+#pragma unroll 4
+            for (int64_t e = rowptr[k] + lane; e < e1; e += lanes) {
+                const cplx a = val[e], v = x[col[e]];
+                sx += a.x * v.x - a.y * v.y; sy += a.x * v.y + a.y * v.x;
+            }
+        }
+        const int wl = lanes < 64 ? lanes : 64;                            // lanes of this row inside one wave
+        for (int o = wl >> 1; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
+        if (lanes > 64) {                                                  // several waves per row: fold through LDS
+            if ((tid & 63) == 0) { psx[wave] = sx; psy[wave] = sy; }
+            __syncthreads();
+            if (lane == 0) {
+                const int nw = lanes >> 6;
+                sx = 0.0; sy = 0.0;
+                for (int w = 0; w < nw; ++w) { sx += psx[wave + w]; sy += psy[wave + w]; }
+            }
+        }
+        if (active && lane == 0) {
+            const int row = rowid[k];
+            const cplx r = make_double2(b[row].x - sx, b[row].y - sy), d = invd[k];
+            x[row] = make_double2(r.x * d.x - r.y * d.y, r.x * d.y + r.y * d.x);
+        }
+        __syncthreads();                          // the rows of level l are visible to level l + 1 (same workgroup)
+    }
+}
+// (tried: loading the descriptor and first matrix entry of level l + 1 while level l is reduced -- slower, 76 -> 104 ms
+// at 2D 513 x 513: the walk is bound by the barrier / reduction chain of 11 000 levels, ~7 us each, not by those loads)
+
+__global__ void k_scatter(const cplx* __restrict__ w, const int* __restrict__ dst, cplx* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[dst[i]] = w[i];
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+
+struct TriFactor {                 // one triangular factor, rows in level order
+    DevBuf<int64_t> rowptr; DevBuf<int> col; DevBuf<cplx> val; DevBuf<int> rowid; DevBuf<cplx> invd; DevBuf<int> lvlptr;
+    std::vector<int> h_lvlptr;     // host copy of the level boundaries
+    int nlevels = 0;
+    struct Seg { bool chain; int l0, l1; };       // launch schedule
+    std::vector<Seg> segs;
+};
+
+static constexpr int NARROW = 128;   // levels with at most this many rows are walked inside a single workgroup
+
+static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const int64_t* col, const double* val, bool lower) {
+    // levels: depth of each row in the dependency graph of the triangular solve
+    std::vector<int> level((size_t)N, 0);
+    std::vector<std::complex<double>> diag((size_t)N, std::complex<double>(0, 0));
+    int nlev = 0;
+    auto scan_row = [&](int64_t r) {
+        int lv = 0; bool have_diag = false;
+        for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+            const int64_t c = col[e];
+            LSFC_REQUIRE(c >= 0 && c < N, "preconditioner factor: column index out of range");
+            if (c == r) { diag[(size_t)r] = std::complex<double>(val[2 * e], val[2 * e + 1]); have_diag = true; continue; }
+            LSFC_REQUIRE(lower ? c < r : c > r, "preconditioner factor: %s factor has an entry on the wrong side of the diagonal (row %lld, col %lld)",
+                         lower ? "L" : "U", (long long)r, (long long)c);
+            lv = std::max(lv, level[(size_t)c] + 1);
+        }
+        LSFC_REQUIRE(have_diag && diag[(size_t)r] != std::complex<double>(0, 0), "preconditioner factor: zero or missing diagonal in row %lld", (long long)r);
+        level[(size_t)r] = lv; nlev = std::max(nlev, lv + 1);
+    };
+    if (lower) for (int64_t r = 0; r < N; ++r) scan_row(r); else for (int64_t r = N - 1; r >= 0; --r) scan_row(r);
+    // counting sort of the rows by level
+    std::vector<int> lvlptr((size_t)nlev + 1, 0);
+    for (int64_t r = 0; r < N; ++r) ++lvlptr[(size_t)level[(size_t)r] + 1];
+    for (int l = 0; l < nlev; ++l) lvlptr[(size_t)l + 1] += lvlptr[(size_t)l];
+    std::vector<int> order((size_t)N), fill(lvlptr.begin(), lvlptr.end() - 1);
+    for (int64_t r = 0; r < N; ++r) order[(size_t)fill[(size_t)level[(size_t)r]]++] = (int)r;
+    // sorted CSR without the diagonal
+    std::vector<int64_t> rp((size_t)N + 1, 0);
+    for (int64_t k = 0; k < N; ++k) { const int64_t r = order[(size_t)k]; rp[(size_t)k + 1] = rp[(size_t)k] + (rowptr[r + 1] - rowptr[r] - 1); }
+    std::vector<int> cc((size_t)rp[(size_t)N]); std::vector<cplx> vv((size_t)rp[(size_t)N]); std::vector<cplx> invd((size_t)N);
+    for (int64_t k = 0; k < N; ++k) {
+        const int64_t r = order[(size_t)k]; int64_t o = rp[(size_t)k];
+        for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+            if (col[e] == r) continue;
+            cc[(size_t)o] = (int)col[e]; vv[(size_t)o] = make_double2(val[2 * e], val[2 * e + 1]); ++o;
+        }
+        const std::complex<double> id = 1.0 / diag[(size_t)r];
+        invd[(size_t)k] = make_double2(id.real(), id.imag());
+    }
+    auto up = [](auto& dev, const auto& host) {
+        dev.alloc(host.size());
+        if (!host.empty()) LSFC_HIP(hipMemcpy(dev.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice));
+    };
+    up(F.rowptr, rp); up(F.col, cc); up(F.val, vv); up(F.rowid, order); up(F.invd, invd); up(F.lvlptr, lvlptr);
+    F.h_lvlptr = lvlptr; F.nlevels = nlev;
+    // schedule: consecutive narrow levels share one single-workgroup launch
+    for (int l = 0; l < nlev;) {
+        const int rows = lvlptr[(size_t)l + 1] - lvlptr[(size_t)l];
+        if (rows > NARROW) { F.segs.push_back({false, l, l + 1}); ++l; continue; }
+        int e = l;
+        while (e < nlev && lvlptr[(size_t)e + 1] - lvlptr[(size_t)e] <= NARROW) ++e;
+        F.segs.push_back({true, l, e}); l = e;
+    }
+}
+
+static void launch_factor(const TriFactor& F, const cplx* b, cplx* x, hipStream_t st) {
+    for (const auto& s : F.segs) {
+        if (s.chain) {
+            hipLaunchKernelGGL(k_trsv_chain, dim3(1), dim3(1024), 0, st, s.l0, s.l1, F.lvlptr.p, F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
+        } else {
+            const int first = F.h_lvlptr[(size_t)s.l0], nrows = F.h_lvlptr[(size_t)s.l0 + 1] - first;
+            hipLaunchKernelGGL(k_trsv_level, dim3((unsigned)(((int64_t)nrows * 8 + 255) / 256)), dim3(256), 0, st, first, nrows,
+                               F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
+        }
+    }
+}
+
+} // namespace lsfc
+
+struct lsfc_precond {
+    int device = 0;
+    int64_t N = 0;
+    hipStream_t stream = nullptr;
+    lsfc::DevBuf<int64_t> a_rowptr; lsfc::DevBuf<int> a_col; lsfc::DevBuf<lsfc::cplx> a_val;     // As, CSR
+    lsfc::DevBuf<int> rgather, cscatter; lsfc::DevBuf<double> rscale;
+    lsfc::TriFactor L, U;
+    lsfc::DevBuf<lsfc::cplx> vin, y0, z, w, vout, hstage;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipStream_t captured_on = nullptr;
+    int launches = 0;
+    ~lsfc_precond() { if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
+};
+
+namespace lsfc {
+
+static void enqueue_all(lsfc_precond* pc, hipStream_t st) {
+    const int N = (int)pc->N;
+    hipLaunchKernelGGL(k_spmv_gather<8>, dim3((unsigned)(((int64_t)N * 8 + 255) / 256)), dim3(256), 0, st, pc->a_rowptr.p, pc->a_col.p, pc->a_val.p,
+                       pc->rgather.p, pc->rscale.p, pc->vin.p, pc->y0.p, N);
+    launch_factor(pc->L, pc->y0.p, pc->z.p, st);
+    launch_factor(pc->U, pc->z.p, pc->w.p, st);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pc->w.p, pc->cscatter.p, pc->vout.p, N);
+}
+
+// v (device, N complex) <- Msp^{-1} (As v), stream-ordered on `st`
+static void precond_apply_dev(lsfc_precond* pc, cplx* v, hipStream_t st) {
+    const size_t bytes = (size_t)pc->N * sizeof(cplx);
+    LSFC_HIP(hipMemcpyAsync(pc->vin.p, v, bytes, hipMemcpyDeviceToDevice, st));
+    if (!pc->exec) {
+        // capture the fixed sequence once (internal buffers only), then replay it
+        hipStream_t cs; LSFC_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            enqueue_all(pc, cs);
+            e = hipStreamEndCapture(cs, &pc->graph);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&pc->exec, pc->graph, nullptr, nullptr, 0);
+        (void)hipStreamDestroy(cs);
+        if (e != hipSuccess) { (void)hipGetLastError(); fail(LSFC_EHIP, "preconditioner: graph capture failed: %s", hipGetErrorString(e)); }
+    }
+    LSFC_HIP(hipGraphLaunch(pc->exec, st));
+    LSFC_HIP(hipMemcpyAsync(v, pc->vout.p, bytes, hipMemcpyDeviceToDevice, st));
+}
+
+} // namespace lsfc
+
+using namespace lsfc;
+
+extern "C" {
+
+int lsfc_precond_create(lsfc_precond** out, int64_t N,
+                        const int64_t* As_rowptr, const int64_t* As_col, const double* As_val,
+                        const int64_t* L_rowptr, const int64_t* L_col, const double* L_val,
+                        const int64_t* U_rowptr, const int64_t* U_col, const double* U_val,
+                        const int64_t* row_gather, const int64_t* col_scatter, const double* row_scale, int device) {
+    return guarded([&] {
+        LSFC_REQUIRE(out, "NULL argument"); *out = nullptr;
+        LSFC_REQUIRE(N >= 1 && N < ((int64_t)1 << 31), "preconditioner: N out of range");
+        LSFC_REQUIRE(As_rowptr && As_col && As_val && L_rowptr && L_col && L_val && U_rowptr && U_col && U_val, "NULL argument");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) fail(LSFC_ENODEV, "no HIP device available: the preconditioner apply has no CPU fallback");
+        LSFC_REQUIRE(device >= 0 && device < count, "device %d out of range (have %d)", device, count);
+        LSFC_HIP(hipSetDevice(device));
+        std::unique_ptr<lsfc_precond> pc(new lsfc_precond());
+        pc->device = device; pc->N = N;
+        // As: CSR, 32-bit columns on the device
+        {
+            const int64_t nnz = As_rowptr[N];
+            std::vector<int> c((size_t)nnz);
+            for (int64_t e = 0; e < nnz; ++e) { LSFC_REQUIRE(As_col[e] >= 0 && As_col[e] < N, "As: column index out of range"); c[(size_t)e] = (int)As_col[e]; }
+            pc->a_rowptr.alloc((size_t)N + 1); pc->a_col.alloc((size_t)nnz); pc->a_val.alloc((size_t)nnz);
+            LSFC_HIP(hipMemcpy(pc->a_rowptr.p, As_rowptr, ((size_t)N + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+            if (nnz) {
+                LSFC_HIP(hipMemcpy(pc->a_col.p, c.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+                LSFC_HIP(hipMemcpy(pc->a_val.p, As_val, (size_t)nnz * sizeof(cplx), hipMemcpyHostToDevice));
+            }
+        }
+        auto perm_up = [&](DevBuf<int>& dev, const int64_t* p, const char* what) {
+            std::vector<int> h((size_t)N); std::vector<char> seen((size_t)N, 0);
+            for (int64_t i = 0; i < N; ++i) {
+                const int64_t v = p ? p[i] : i;
+                LSFC_REQUIRE(v >= 0 && v < N && !seen[(size_t)v], "preconditioner: %s is not a permutation", what);
+                seen[(size_t)v] = 1; h[(size_t)i] = (int)v;
+            }
+            dev.alloc((size_t)N);
+            LSFC_HIP(hipMemcpy(dev.p, h.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
+        };
+        perm_up(pc->rgather, row_gather, "row_gather");
+        perm_up(pc->cscatter, col_scatter, "col_scatter");
+        if (row_scale) { pc->rscale.alloc((size_t)N); LSFC_HIP(hipMemcpy(pc->rscale.p, row_scale, (size_t)N * sizeof(double), hipMemcpyHostToDevice)); }
+        build_factor(pc->L, N, L_rowptr, L_col, L_val, true);
+        build_factor(pc->U, N, U_rowptr, U_col, U_val, false);
+        for (DevBuf<cplx>* b : { &pc->vin, &pc->y0, &pc->z, &pc->w, &pc->vout }) { b->alloc((size_t)N); LSFC_HIP(hipMemset(b->p, 0, b->bytes())); }
+        pc->launches = 2 + (int)pc->L.segs.size() + (int)pc->U.segs.size();
+        *out = pc.release();
+    });
+}
+
+int lsfc_precond_destroy(lsfc_precond* pc) {
+    return guarded([&] { if (pc) { (void)hipSetDevice(pc->device); (void)hipDeviceSynchronize(); delete pc; } });
+}
+
+int lsfc_precond_set_stream(lsfc_precond* pc, void* stream) {
+    return guarded([&] { LSFC_REQUIRE(pc, "NULL preconditioner"); pc->stream = (hipStream_t)stream; });
+}
+
+int lsfc_precond_apply(lsfc_precond* pc, double* v, int memspace) {
+    return guarded([&] {
+        LSFC_REQUIRE(pc && v, "NULL argument");
+        LSFC_REQUIRE(memspace == LSFC_MEM_HOST || memspace == LSFC_MEM_DEVICE, "bad memspace %d", memspace);
+        LSFC_HIP(hipSetDevice(pc->device));
+        if (memspace == LSFC_MEM_DEVICE) { precond_apply_dev(pc, (cplx*)v, pc->stream); return; }
+        if (pc->hstage.n < (size_t)pc->N) pc->hstage.alloc((size_t)pc->N);
+        const size_t bytes = (size_t)pc->N * sizeof(cplx);
+        LSFC_HIP(hipMemcpyAsync(pc->hstage.p, v, bytes, hipMemcpyHostToDevice, pc->stream));
+        precond_apply_dev(pc, pc->hstage.p, pc->stream);
+        LSFC_HIP(hipMemcpyAsync(v, pc->hstage.p, bytes, hipMemcpyDeviceToHost, pc->stream));
+        LSFC_HIP(hipStreamSynchronize(pc->stream));
+    });
+}
+
+/* lsfc_precond_fn-compatible entry: opts.precond = lsfc_precond_callback, opts.precond_user = pc,
+ * opts.precond_on_device = 1 (v is the device-resident Krylov vector; work is enqueued on pc's stream). */
+int lsfc_precond_callback(void* user, double* v, int64_t n) {
+    lsfc_precond* pc = (lsfc_precond*)user;
+    if (!pc || n != pc->N) { set_last_error("preconditioner callback: size mismatch (%lld vs %lld)", (long long)n, pc ? (long long)pc->N : -1LL); return 1; }
+    return lsfc_precond_apply(pc, v, LSFC_MEM_DEVICE) == LSFC_OK ? 0 : 1;
+}
+
+int lsfc_precond_stats(const lsfc_precond* pc, int64_t* levels_L, int64_t* levels_U, int64_t* launches) {
+    return guarded([&] {
+        LSFC_REQUIRE(pc, "NULL preconditioner");
+        if (levels_L) *levels_L = pc->L.nlevels;
+        if (levels_U) *levels_U = pc->U.nlevels;
+        if (launches) *launches = pc->launches;
+    });
+}
+
+} // extern "C"

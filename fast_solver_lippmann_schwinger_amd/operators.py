@@ -366,7 +366,21 @@ def gmres_(x, A, b, Pl=None, abstol=0.0, reltol=None, restart=None, maxiter=None
     opts.orth = _ORTH[orth_meth]
     opts.initially_zero = 1 if initially_zero else 0
     err = []
-    if Pl is not None:
+    native_pc = getattr(Pl, "_pc", None) if Pl is not None else None
+    if native_pc is not None:
+        # device-resident SparsifyingPreconditioner: the library calls it directly, no Python in the loop; the Krylov
+        # basis lives on the device wherever x and b live, so the preconditioner sees device vectors either way
+        if sx == L.LSFC_MEM_DEVICE:
+            import torch
+            Pl.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
+        else:
+            L.check(L.load().lsfc_plan_set_stream(A._plan, None))
+            Pl.set_stream(0)
+        lib = L.load()
+        opts.precond = C.cast(lib.lsfc_precond_callback, L.PRECOND_FN)
+        opts.precond_user = native_pc
+        opts.precond_on_device = 1
+    elif Pl is not None:
         def _cb(user, v, n):
             try:
                 if Pl_on_device:

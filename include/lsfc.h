@@ -177,6 +177,35 @@ typedef struct lsfc_gmres_result {
 int lsfc_gmres(lsfc_plan* plan, double* x, const double* b, const lsfc_gmres_opts* opts,
                double* resnorm, int64_t resnorm_cap, lsfc_gmres_result* result, int memspace);
 
+/* ---- device-resident SparsifyingPreconditioner apply ------------------------ */
+
+/* The reference's preconditioner (src/preconditioner.jl:27-58) holds two sparse matrices and a sparse LU:
+ *     SparsifyingPreconditioner(Msp, As):  MspInv = lu(Msp)          (:35, UMFPACK)
+ *     ldiv!(P, b):  b[:] = MspInv \ (As * b)                          (:132-170)
+ * lsfc_precond keeps As and the LU factors on the device and applies v <- Msp^{-1} (As v) there (CSR SpMV, two
+ * level-scheduled sparse triangular solves replayed from one hipGraph), so the Krylov vector does not cross PCIe.
+ * The factorisation stays with the caller (host): with (Rs .* Msp)[p, q] = L U pass
+ *     L, U         CSR, 0-based, diagonals stored (L's unit diagonal included), values interleaved complex
+ *     row_gather   k -> row of Msp that becomes row k of L U   (Julia: F.p .- 1;  NULL = identity)
+ *     col_scatter  k -> column of Msp behind column k of L U   (Julia: F.q .- 1;  NULL = identity)
+ *     row_scale    Rs (Julia: F.Rs), NULL = ones
+ * As: CSR, 0-based, N rows.  All index arrays are int64_t. */
+typedef struct lsfc_precond lsfc_precond;
+int lsfc_precond_create(lsfc_precond** out, int64_t N,
+                        const int64_t* As_rowptr, const int64_t* As_col, const double* As_val,
+                        const int64_t* L_rowptr, const int64_t* L_col, const double* L_val,
+                        const int64_t* U_rowptr, const int64_t* U_col, const double* U_val,
+                        const int64_t* row_gather, const int64_t* col_scatter, const double* row_scale, int device);
+int lsfc_precond_destroy(lsfc_precond* pc);
+/* hipStream_t the apply is enqueued on (NULL = legacy default stream); use the plan's stream under lsfc_gmres */
+int lsfc_precond_set_stream(lsfc_precond* pc, void* stream);
+/* v <- Msp^{-1} (As v); LSFC_MEM_DEVICE: stream-ordered, returns without synchronising */
+int lsfc_precond_apply(lsfc_precond* pc, double* v, int memspace);
+/* lsfc_precond_fn for lsfc_gmres_opts: precond = lsfc_precond_callback, precond_user = pc, precond_on_device = 1 */
+int lsfc_precond_callback(void* user, double* v, int64_t n);
+/* dependency levels of the two triangular solves and kernel launches captured in the graph */
+int lsfc_precond_stats(const lsfc_precond* pc, int64_t* levels_L, int64_t* levels_U, int64_t* launches);
+
 /* ---- streams, timing, profiling ------------------------------------------ */
 
 /* Run the plan on a caller-owned hipStream_t (NULL = the legacy default stream). */

@@ -489,3 +489,28 @@ def gaussian_bump(*coords):
 def random_vector(N, seed=20250224):
     rng = np.random.default_rng(seed)
     return rng.standard_normal(N) + 1j * rng.standard_normal(N)
+
+
+# ----------------------------------------------------------------------------
+# SparsifyingPreconditioner apply: src/preconditioner.jl:27-58 (lu(Msp)), :132-170 (ldiv!)
+# ----------------------------------------------------------------------------
+class SparsifyingPreconditioner:
+    """``b <- MspInv \\ (As * b)`` with ``MspInv = lu(Msp)`` (src/preconditioner.jl:35, 139, 160).  scipy's SuperLU stands
+    in for UMFPACK: any LU of Msp applies the same operator up to rounding."""
+
+    def __init__(self, Msp, As):
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+        self.Msp = sp.csc_matrix(Msp, dtype=np.complex128)
+        self.As = sp.csr_matrix(As, dtype=np.complex128)
+        self.MspInv = spla.splu(self.Msp)
+
+    def solve(self, b):                      # \\(M, b), :132-145
+        return self.MspInv.solve(self.As @ np.asarray(b, dtype=np.complex128))
+
+    def ldiv_(self, b):                      # ldiv!(M, b), :147-170
+        b[:] = self.solve(b)
+        return b
+
+    def __call__(self, b):
+        self.ldiv_(b)

@@ -65,3 +65,19 @@ def case_3d(name):
 
 def plane_wave(k, X):
     return np.exp(1j * k * X)
+
+
+def sparsifying_pair_2d(n, h, k, nu_flat, eps=0.5):
+    """Synthetic (Msp, As) of the reference's structure (src/preconditioner.jl:27-31; the assembly of the real pair,
+    src/SparsifyingMatrix2D.jl, is out of scope): with (Lap + k^2) G = -delta the sparsifier As = -(Lap_h + k^2 + i eps)
+    turns A = I + k^2 G nu into the sparse Msp = As + k^2 diag(nu) up to discretisation error (5-point Laplacian,
+    Dirichlet box).  Column-major grid, x fastest."""
+    import scipy.sparse as sp
+    e = np.ones(n)
+    T = sp.diags([e[:-1], -2 * e, e[:-1]], [-1, 0, 1]) / h**2
+    I = sp.identity(n)
+    lap = sp.kron(I, T) + sp.kron(T, I)
+    N = n * n
+    As = (-(lap + (k**2 + 1j * eps) * sp.identity(N))).tocsr().astype(np.complex128)
+    Msp = (As + k**2 * sp.diags(np.asarray(nu_flat, dtype=np.float64))).tocsc().astype(np.complex128)
+    return Msp, As

@@ -141,6 +141,44 @@ def bench_hf_gmres(n=512, restart=30, maxiter=30):
     return {"config": f"3D n={n} omega=64pi patched symbol, GMRES({restart}) capped at {maxiter} iterations", "solves": out}
 
 
+def bench_precond(n=513):
+    """SparsifyingPreconditioner apply b <- Msp^-1 (As b) (src/preconditioner.jl:132-170) on the
+    device against the host sparse-LU solve, 2D n x n, synthetic (Msp, As) of the reference's structure (tests/cases.py);
+    then the GMRES inner step with the preconditioner on the device, and on the host through the callback."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import cases
+    import scipy.sparse.linalg as spla
+    h = 1.0 / (n - 1); x = -0.5 + h * np.arange(n); k = 0.5 / h
+    X = np.tile(x, n); Y = np.repeat(x, n)
+    nu = bump(X, Y)
+    Msp, As = cases.sparsifying_pair_2d(n, h, k, nu)
+    t0 = time.time(); lu = spla.splu(Msp); t_lu = time.time() - t0
+    t0 = time.time(); P = lsfc.SparsifyingPreconditioner(Msp, As, lu=lu); t_up = time.time() - t0
+    N = n * n
+    b = np.random.default_rng(0).standard_normal(N) + 1j * np.random.default_rng(1).standard_normal(N)
+    t0 = time.time()
+    for _ in range(3): ref = lu.solve(As @ b)
+    t_host = (time.time() - t0) / 3
+    v = torch.from_numpy(b).cuda(); P.ldiv_(v); torch.cuda.synchronize()
+    err = float(np.linalg.norm(v.cpu().numpy() - ref) / np.linalg.norm(ref))
+    v = torch.from_numpy(b).cuda(); torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(20): P.ldiv_(v)
+    torch.cuda.synchronize(); t_dev = (time.time() - t0) / 20
+    M = lsfc.buildFastConvolution(x, x, h, k, lambda X_, Y_: nu, quadRule="Greengard_Vico")
+    u_inc = np.exp(1j * k * X)
+    rhs = torch.from_numpy(-k**2 * lsfc.FFTconvolution(M, nu * u_inc)).cuda()
+    out = {}
+    for name, Pl in [("preconditioner on the device", P), ("preconditioner on the host (callback)", lambda v_: v_.__setitem__(slice(None), lu.solve(As @ v_))), ("none", None)]:
+        u = torch.zeros_like(rhs); torch.cuda.synchronize(); t0 = time.time()
+        u, hist = lsfc.gmres_(u, M, rhs, Pl=Pl, restart=30, reltol=1e-6, maxiter=30, log=True, orth_meth="ClassicalGramSchmidt")
+        torch.cuda.synchronize(); t = time.time() - t0
+        out[name] = {"iters": hist.iters, "converged": hist.isconverged, "ms_per_iteration": 1e3 * t / max(hist.iters, 1)}
+    st = P.stats()
+    return {"config": f"2D n={n} SparsifyingPreconditioner apply (synthetic Msp/As pair)", "N": N, "nnz_L+U": st["nnz_L"] + st["nnz_U"],
+            "levels": [st["levels_L"], st["levels_U"]], "graph_kernel_nodes": st["launches"], "host_lu_factor_s": t_lu, "upload_and_analysis_s": t_up,
+            "host_apply_ms": 1e3 * t_host, "device_apply_ms": 1e3 * t_dev, "device_vs_host_rel_err": err, "gmres": out}
+
+
 def bench_host_vectors(n=512):
     """PCIe-inclusive rate: the same apply with HOST-resident x and y (LSFC_MEM_HOST), as the Julia wrapper's `*` does."""
     h = 1.0 / n
@@ -166,6 +204,8 @@ if __name__ == "__main__":
     if "gmres512" in what: res.append(bench_gmres(512))
     if "small" in what: res.extend(bench_small())
     if "hfgmres" in what: res.append(bench_hf_gmres())
+    if "precond" in what: res.append(bench_precond())
+    if "precond257" in what: res.append(bench_precond(257))
     if "host" in what: res.append(bench_host_vectors())
     for r in res:
         print(json.dumps(r), flush=True)
