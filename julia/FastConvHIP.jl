@@ -106,6 +106,34 @@ function sampleG3D(k, X, Y, Z, indS, M::FastMHIP)
 end
 sampleGConv(k, X, Y, indS, M::FastMHIP) = sampleG3D(k, X, Y, nothing, indS, M)
 
+# SparsifyingPreconditioner(Msp, As) with the apply on the device -- src/preconditioner.jl:27-58, 132-170.
+# lu(Msp) stays on the host (UMFPACK, as in the reference); its factors go to the device once:
+# (F.Rs .* Msp)[F.p, F.q] == F.L * F.U.  CSR arrays of a SparseMatrixCSC X are the CSC arrays of transpose(X).
+using SparseArrays
+mutable struct SparsifyingPreconditionerHIP
+    pc::Ptr{Cvoid}
+    N::Int64
+end
+_csr(X) = (T = sparse(transpose(X)); (Int64.(T.colptr .- 1), Int64.(T.rowval .- 1), Vector{Complex{Float64}}(T.nzval)))
+function SparsifyingPreconditionerHIP(Msp::SparseMatrixCSC{Complex{Float64},Int64}, As::SparseMatrixCSC{Complex{Float64},Int64}; device=0)
+    F = lu(Msp); N = size(Msp, 1)
+    (ap, ac, av) = _csr(As); (lp, lc, lv) = _csr(F.L); (up, uc, uv) = _csr(F.U)
+    p = Int64.(F.p .- 1); q = Int64.(F.q .- 1); Rs = Vector{Float64}(F.Rs)
+    pc = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:lsfc_precond_create, liblsfc), Cint,
+                (Ref{Ptr{Cvoid}}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Complex{Float64}}, Ptr{Int64}, Ptr{Int64}, Ptr{Complex{Float64}},
+                 Ptr{Int64}, Ptr{Int64}, Ptr{Complex{Float64}}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint),
+                pc, N, ap, ac, av, lp, lc, lv, up, uc, uv, p, q, Rs, device))
+    P = SparsifyingPreconditionerHIP(pc[], N)
+    finalizer(P -> ccall((:lsfc_precond_destroy, liblsfc), Cint, (Ptr{Cvoid},), P.pc), P)
+    return P
+end
+# ldiv!(P, b): host vector in, host vector out (staged over PCIe); inside gmres_hip! the device path is used instead
+function LinearAlgebra.ldiv!(P::SparsifyingPreconditionerHIP, b::Vector{Complex{Float64}})
+    check(ccall((:lsfc_precond_apply, liblsfc), Cint, (Ptr{Cvoid}, Ptr{Complex{Float64}}, Cint), P.pc, b, 0)); b
+end
+Base.:\(P::SparsifyingPreconditionerHIP, b::Vector{Complex{Float64}}) = ldiv!(P, copy(b))
+
 # Device-side GMRES with a host preconditioner: Pl is anything with the two-argument ldiv!(Pl, v)
 # (src/preconditioner.jl:147-170), passed through @cfunction.
 struct GmresOpts
@@ -123,8 +151,13 @@ end
 function gmres_hip!(x::Vector{Complex{Float64}}, M::FastMHIP, b::Vector{Complex{Float64}}; Pl=nothing, restart=min(20, length(b)),
                     maxiter=length(b), reltol=sqrt(eps(Float64)), abstol=0.0, initially_zero=false)
     box = Ref{Any}(Pl)
-    cb = Pl === nothing ? C_NULL : @cfunction(_precond_trampoline, Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64))
-    opts = Ref(GmresOpts(restart, maxiter, reltol, abstol, 0, initially_zero ? 1 : 0, cb, Pl === nothing ? C_NULL : pointer_from_objref(box), 0))
+    if Pl isa SparsifyingPreconditionerHIP        # applied on the device by the library itself: no PCIe, no Julia in the loop
+        cb = cglobal((:lsfc_precond_callback, liblsfc)); user = Pl.pc; ondev = Cint(1)
+    else
+        cb = Pl === nothing ? C_NULL : @cfunction(_precond_trampoline, Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64))
+        user = Pl === nothing ? C_NULL : pointer_from_objref(box); ondev = Cint(0)
+    end
+    opts = Ref(GmresOpts(restart, maxiter, reltol, abstol, 0, initially_zero ? 1 : 0, cb, user, ondev))
     res = Ref(GmresResult(0, 0, 0, 0.0)); resnorm = zeros(Float64, maxiter)
     GC.@preserve box begin
         rc = ccall((:lsfc_gmres, liblsfc), Cint,
