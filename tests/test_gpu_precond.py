@@ -67,6 +67,37 @@ def test_general_lu_with_permutations_and_wide_levels(lsfc):
     assert st["levels_L"] >= bs - 1 and st["launches"] >= 4
 
 
+def test_row_scaling_through_the_c_abi(lsfc):
+    # Julia's lu(Msp) (UMFPACK) factors a row-scaled matrix, (Rs .* Msp)[p, q] = L U; the C ABI takes Rs as row_scale
+    import ctypes as C
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from fast_solver_lippmann_schwinger_amd import _lib as L
+    from fast_solver_lippmann_schwinger_amd.preconditioner import _csr_arrays
+    (Msp, As), _ = _pair(21)
+    N = Msp.shape[0]
+    Rs = np.random.default_rng(3).uniform(0.5, 2.0, N)
+    lu = spla.splu((sp.diags(Rs) @ Msp).tocsc())
+    rg = np.empty(N, np.int64); rg[lu.perm_r] = np.arange(N)
+    cs = np.empty(N, np.int64); cs[lu.perm_c] = np.arange(N)
+    arrs = [*_csr_arrays(As), *_csr_arrays(lu.L), *_csr_arrays(lu.U), rg, cs, Rs]
+    pc = C.c_void_p()
+    L.check(L.load().lsfc_precond_create(C.byref(pc), N, *[a.ctypes.data_as(C.c_void_p) for a in arrs], 0))
+    b = o.random_vector(N)
+    v = b.copy()
+    L.check(L.load().lsfc_precond_apply(pc, v.ctypes.data_as(C.c_void_p), 0))
+    assert rel_err(v, o.SparsifyingPreconditioner(Msp, As).solve(b)) < 1e-10
+    # malformed factors are refused, not solved: an upper entry in L, a permutation with a repeated index
+    pc2 = C.c_void_p()
+    args = [a.ctypes.data_as(C.c_void_p) for a in arrs]
+    args_bad = list(args); args_bad[9] = np.zeros(N, np.int64).ctypes.data_as(C.c_void_p)      # row_gather all zero
+    assert L.load().lsfc_precond_create(C.byref(pc2), N, *args_bad, 0) == -1
+    Lt = _csr_arrays(lu.U)                                                                      # U passed as "L"
+    args_bad = list(args); args_bad[3:6] = [a.ctypes.data_as(C.c_void_p) for a in Lt]
+    assert L.load().lsfc_precond_create(C.byref(pc2), N, *args_bad, 0) == -1
+    L.load().lsfc_precond_destroy(pc)
+
+
 def test_argument_errors(lsfc):
     import scipy.sparse as sp
     (Msp, As), _ = _pair(9)
