@@ -1,9 +1,15 @@
 """Developer harness: sweep of the fused-pass knobs (split exchange, symbol prefetch, LDS twiddle table) and of the
 split exchanges of the x / y passes.  usage: python tools/sweep_knobs.py [2d] n [n ...]"""
-import os, sys, itertools
-import numpy as np, torch
-sys.path.insert(0, "/root/repo")
-import fast_solver_lippmann_schwinger_amd as lsfc
+import itertools
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fast_solver_lippmann_schwinger_amd as lsfc  # noqa: E402
+
 BASE = dict(split_x=1, split_s=1, split_z=-1, sym_prefetch=-1, ytile_g=0, ytile_z=0, z_half=-1, tw_lds=1)
 DIM = 2 if "2d" in sys.argv[1:] else 3
 for n in [int(a) for a in sys.argv[1:] if a != "2d"]:
