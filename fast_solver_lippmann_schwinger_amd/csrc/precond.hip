@@ -69,19 +69,27 @@ __global__ void k_trsv_level(int first, int nrows, const int64_t* __restrict__ r
     trsv_row<8>(first + g, lane, rowptr, col, val, rowid, invd, b, x);
 }
 
-// a run of narrow levels [l0, l1) in ONE workgroup of 1024 threads: level after level, a barrier in between.
-// Every level of the run has at most 128 rows.  The tail of a sparse LU factor is deep and thin -- at 2D 257 x 257 a
-// third of the fill sits in 1391 levels of ONE row with ~740 entries each -- so the lanes are dealt out per level:
-// 1024 / (rows rounded up to a power of two) lanes per row, all 1024 on a single row; sums are folded by wave
-// shuffles and, beyond one wave per row, through LDS.  The critical path of a level is then one dependent pair of
-// loads (col -> x[col]) and a reduction, not a loop over the row.
+// a run of narrow levels in ONE workgroup of 1024 threads, a barrier between steps.  The tail of a sparse LU factor
+// is deep and thin -- at 2D 257 x 257 a third of the fill sits in 1391 levels of ONE row with ~740 entries each (the
+// dense trailing separator blocks) -- so
+//  * the lanes are dealt out per step: 1024 / (rows rounded up to a power of two) lanes per row, all 1024 on a single
+//    row; sums are folded by wave shuffles and, beyond one wave per row, through LDS;
+//  * consecutive thin levels are fused into GROUPS of at most 16 rows: the entries that couple rows of the same group
+//    are taken out of the CSR rows into a dense 16 x 16 block at set-up, every row of the group sums its remaining
+//    (external) entries at the same time, and one wave then resolves the little dense triangle in registers
+//    (16 shuffle steps, no memory latency).  One barrier-bound step thus retires up to 16 dependency levels.
+// A group with dense offset -1 is a single level (independent rows).
+static constexpr int GROUP_ROWS = 16;
+
 __global__ __launch_bounds__(1024)
-void k_trsv_chain(int l0, int l1, const int* __restrict__ lvlptr, const int64_t* __restrict__ rowptr, const int* __restrict__ col,
-                  const cplx* __restrict__ val, const int* __restrict__ rowid, const cplx* __restrict__ invd, const cplx* __restrict__ b, cplx* x) {
-    __shared__ double psx[16], psy[16];
+void k_trsv_chain(int g0, int g1, const int* __restrict__ grpptr, const int* __restrict__ grpcnt, const int* __restrict__ grpdense,
+                  const cplx* __restrict__ dense,
+                  const int64_t* __restrict__ rowptr, const int* __restrict__ col, const cplx* __restrict__ val,
+                  const int* __restrict__ rowid, const cplx* __restrict__ invd, const cplx* __restrict__ b, cplx* x) {
+    __shared__ double psx[16], psy[16], rx[GROUP_ROWS], ry[GROUP_ROWS];
     const int tid = threadIdx.x, wave = tid >> 6;
-    for (int l = l0; l < l1; ++l) {
-        const int first = lvlptr[l], nrows = lvlptr[l + 1] - first;       // uniform over the workgroup
+    for (int gi = g0; gi < g1; ++gi) {
+        const int first = grpptr[gi], nrows = grpcnt[gi], dofs = grpdense[gi];     // uniform over the workgroup
         int p2 = 1; while (p2 < nrows) p2 <<= 1;
         const int lanes = 1024 / p2;                                       // 8 ... 1024, a power of two
         const int g = tid / lanes, lane = tid % lanes;
@@ -107,16 +115,41 @@ void k_trsv_chain(int l0, int l1, const int* __restrict__ lvlptr, const int64_t*
                 for (int w = 0; w < nw; ++w) { sx += psx[wave + w]; sy += psy[wave + w]; }
             }
         }
-        if (active && lane == 0) {
-            const int row = rowid[k];
-            const cplx r = make_double2(b[row].x - sx, b[row].y - sy), d = invd[k];
-            x[row] = make_double2(r.x * d.x - r.y * d.y, r.x * d.y + r.y * d.x);
+        if (dofs < 0) {                                                    // independent rows
+            if (active && lane == 0) {
+                const int row = rowid[k];
+                const cplx r = make_double2(b[row].x - sx, b[row].y - sy), d = invd[k];
+                x[row] = make_double2(r.x * d.x - r.y * d.y, r.x * d.y + r.y * d.x);
+            }
+        } else {                                                           // rows coupled through the dense block
+            if (active && lane == 0) { const int row = rowid[k]; rx[g] = b[row].x - sx; ry[g] = b[row].y - sy; }
+            __syncthreads();
+            if (wave == 0) {
+                const int i = tid;                                         // local row
+                const bool mine = i < nrows;
+                double ax = mine ? rx[i] : 0.0, ay = mine ? ry[i] : 0.0;
+                const cplx di = mine ? invd[first + i] : make_double2(0.0, 0.0);
+                cplx drow[GROUP_ROWS];
+#pragma unroll
+                for (int j = 0; j < GROUP_ROWS; ++j) drow[j] = (mine && j < i) ? dense[(int64_t)dofs + i * GROUP_ROWS + j] : make_double2(0.0, 0.0);
+                double myx = 0.0, myy = 0.0;
+#pragma unroll
+                for (int j = 0; j < GROUP_ROWS; ++j) {
+                    if (j < nrows) {                                       // uniform
+                        const double tx = ax * di.x - ay * di.y, ty = ax * di.y + ay * di.x;      // x_j on lane j
+                        const double xjx = __shfl(tx, j, 64), xjy = __shfl(ty, j, 64);
+                        if (i == j) { myx = xjx; myy = xjy; }
+                        ax -= drow[j].x * xjx - drow[j].y * xjy; ay -= drow[j].x * xjy + drow[j].y * xjx;
+                    }
+                }
+                if (mine) x[rowid[first + i]] = make_double2(myx, myy);
+            }
         }
-        __syncthreads();                          // the rows of level l are visible to level l + 1 (same workgroup)
+        __syncthreads();                          // this step's rows are visible to the next step (same workgroup)
     }
 }
-// (tried: loading the descriptor and first matrix entry of level l + 1 while level l is reduced -- slower, 76 -> 104 ms
-// at 2D 513 x 513: the walk is bound by the barrier / reduction chain of 11 000 levels, ~7 us each, not by those loads)
+// (tried: loading the descriptor and first matrix entry of the next step while the current one is reduced -- slower:
+// the walk is bound by the barrier / reduction chain, not by those loads)
 
 __global__ void k_scatter(const cplx* __restrict__ w, const int* __restrict__ dst, cplx* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,8 +162,10 @@ struct TriFactor {                 // one triangular factor, rows in level order
     DevBuf<int64_t> rowptr; DevBuf<int> col; DevBuf<cplx> val; DevBuf<int> rowid; DevBuf<cplx> invd; DevBuf<int> lvlptr;
     std::vector<int> h_lvlptr;     // host copy of the level boundaries
     int nlevels = 0;
-    struct Seg { bool chain; int l0, l1; };       // launch schedule
+    struct Seg { bool chain; int l0, l1; };       // launch schedule: a wide level [l0, l0 + 1) or a run of groups [l0, l1)
     std::vector<Seg> segs;
+    DevBuf<int> grpptr, grpcnt, grpdense; DevBuf<cplx> dense;            // groups of the chain segments
+    int ngroups = 0;
 };
 
 static constexpr int NARROW = 128;   // levels with at most this many rows are walked inside a single workgroup
@@ -160,16 +195,50 @@ static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const i
     for (int l = 0; l < nlev; ++l) lvlptr[(size_t)l + 1] += lvlptr[(size_t)l];
     std::vector<int> order((size_t)N), fill(lvlptr.begin(), lvlptr.end() - 1);
     for (int64_t r = 0; r < N; ++r) order[(size_t)fill[(size_t)level[(size_t)r]]++] = (int)r;
-    // sorted CSR without the diagonal
+    // schedule: a wide level is one launch; a run of consecutive narrow levels is one single-workgroup launch that walks
+    // GROUPS: consecutive thin levels with at most GROUP_ROWS rows together, coupled through a dense block
+    std::vector<int> grpptr, grpcnt, grpdense;      // group -> first sorted row, rows, dense offset (-1: a single level)
+    std::vector<int> group_of((size_t)N, -1);       // sorted row -> group, for the rows of multi-level groups only
+    int64_t ndense = 0;
+    for (int l = 0; l < nlev;) {
+        const int rows = lvlptr[(size_t)l + 1] - lvlptr[(size_t)l];
+        if (rows > NARROW) { F.segs.push_back({false, l, l + 1}); ++l; continue; }
+        const int gfirst = (int)grpptr.size();
+        while (l < nlev && lvlptr[(size_t)l + 1] - lvlptr[(size_t)l] <= NARROW) {
+            int e = l + 1, tot = lvlptr[(size_t)l + 1] - lvlptr[(size_t)l];
+            while (e < nlev && tot + (lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]) <= GROUP_ROWS) { tot += lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]; ++e; }
+            grpptr.push_back(lvlptr[(size_t)l]); grpcnt.push_back(tot);
+            if (e > l + 1) {                        // several levels: rows coupled through a dense block
+                for (int k = lvlptr[(size_t)l]; k < lvlptr[(size_t)e]; ++k) group_of[(size_t)k] = (int)grpdense.size();
+                grpdense.push_back((int)ndense); ndense += GROUP_ROWS * GROUP_ROWS;
+            } else grpdense.push_back(-1);
+            l = e;
+        }
+        F.segs.push_back({true, gfirst, (int)grpptr.size()});
+    }
+    LSFC_REQUIRE(ndense < ((int64_t)1 << 31), "preconditioner factor: too many dense blocks");
+    // sorted CSR without the diagonal; entries coupling two rows of the same group go to that group's dense block
+    std::vector<int> sorted_of((size_t)N);
+    for (int64_t k = 0; k < N; ++k) sorted_of[(size_t)order[(size_t)k]] = (int)k;
+    std::vector<cplx> dense((size_t)ndense, make_double2(0.0, 0.0));
     std::vector<int64_t> rp((size_t)N + 1, 0);
-    for (int64_t k = 0; k < N; ++k) { const int64_t r = order[(size_t)k]; rp[(size_t)k + 1] = rp[(size_t)k] + (rowptr[r + 1] - rowptr[r] - 1); }
-    std::vector<int> cc((size_t)rp[(size_t)N]); std::vector<cplx> vv((size_t)rp[(size_t)N]); std::vector<cplx> invd((size_t)N);
+    std::vector<int> cc; std::vector<cplx> vv; std::vector<cplx> invd((size_t)N);
+    cc.reserve((size_t)(rowptr[N])); vv.reserve((size_t)(rowptr[N]));
     for (int64_t k = 0; k < N; ++k) {
-        const int64_t r = order[(size_t)k]; int64_t o = rp[(size_t)k];
+        const int64_t r = order[(size_t)k];
+        const int grp = group_of[(size_t)k];
         for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
             if (col[e] == r) continue;
-            cc[(size_t)o] = (int)col[e]; vv[(size_t)o] = make_double2(val[2 * e], val[2 * e + 1]); ++o;
+            const int kc = sorted_of[(size_t)col[e]];
+            if (grp >= 0 && group_of[(size_t)kc] == grp) {
+                const int i = (int)k - grpptr[(size_t)grp], j = kc - grpptr[(size_t)grp];       // local indices, j < i
+                LSFC_REQUIRE(j >= 0 && j < i && i < GROUP_ROWS, "internal: dense block index (%d, %d)", i, j);
+                dense[(size_t)grpdense[(size_t)grp] + (size_t)i * GROUP_ROWS + (size_t)j] = make_double2(val[2 * e], val[2 * e + 1]);
+                continue;
+            }
+            cc.push_back((int)col[e]); vv.push_back(make_double2(val[2 * e], val[2 * e + 1]));
         }
+        rp[(size_t)k + 1] = (int64_t)cc.size();
         const std::complex<double> id = 1.0 / diag[(size_t)r];
         invd[(size_t)k] = make_double2(id.real(), id.imag());
     }
@@ -178,21 +247,15 @@ static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const i
         if (!host.empty()) LSFC_HIP(hipMemcpy(dev.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice));
     };
     up(F.rowptr, rp); up(F.col, cc); up(F.val, vv); up(F.rowid, order); up(F.invd, invd); up(F.lvlptr, lvlptr);
-    F.h_lvlptr = lvlptr; F.nlevels = nlev;
-    // schedule: consecutive narrow levels share one single-workgroup launch
-    for (int l = 0; l < nlev;) {
-        const int rows = lvlptr[(size_t)l + 1] - lvlptr[(size_t)l];
-        if (rows > NARROW) { F.segs.push_back({false, l, l + 1}); ++l; continue; }
-        int e = l;
-        while (e < nlev && lvlptr[(size_t)e + 1] - lvlptr[(size_t)e] <= NARROW) ++e;
-        F.segs.push_back({true, l, e}); l = e;
-    }
+    up(F.grpptr, grpptr); up(F.grpcnt, grpcnt); up(F.grpdense, grpdense); up(F.dense, dense);
+    F.h_lvlptr = lvlptr; F.nlevels = nlev; F.ngroups = (int)grpdense.size();
 }
 
 static void launch_factor(const TriFactor& F, const cplx* b, cplx* x, hipStream_t st) {
     for (const auto& s : F.segs) {
         if (s.chain) {
-            hipLaunchKernelGGL(k_trsv_chain, dim3(1), dim3(1024), 0, st, s.l0, s.l1, F.lvlptr.p, F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
+            hipLaunchKernelGGL(k_trsv_chain, dim3(1), dim3(1024), 0, st, s.l0, s.l1, F.grpptr.p, F.grpcnt.p, F.grpdense.p, F.dense.p,
+                               F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
         } else {
             const int first = F.h_lvlptr[(size_t)s.l0], nrows = F.h_lvlptr[(size_t)s.l0 + 1] - first;
             hipLaunchKernelGGL(k_trsv_level, dim3((unsigned)(((int64_t)nrows * 8 + 255) / 256)), dim3(256), 0, st, first, nrows,
