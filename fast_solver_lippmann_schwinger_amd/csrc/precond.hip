@@ -61,12 +61,14 @@ __device__ __forceinline__ void trsv_row(int k, int lane, const int64_t* __restr
     }
 }
 
-// one wide level: rows [first, first + nrows) of the sorted order, 8 lanes per row
+// one level as its own launch over many workgroups: rows [first, first + nrows) of the sorted order, LPR lanes per row
+// (8 for the short rows of the early levels, a whole wave for the long rows of the fill)
+template <int LPR>
 __global__ void k_trsv_level(int first, int nrows, const int64_t* __restrict__ rowptr, const int* __restrict__ col, const cplx* __restrict__ val,
                              const int* __restrict__ rowid, const cplx* __restrict__ invd, const cplx* __restrict__ b, cplx* x) {
-    const int g = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / 8), lane = threadIdx.x % 8;
+    const int g = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / LPR), lane = threadIdx.x % LPR;
     if (g >= nrows) return;
-    trsv_row<8>(first + g, lane, rowptr, col, val, rowid, invd, b, x);
+    trsv_row<LPR>(first + g, lane, rowptr, col, val, rowid, invd, b, x);
 }
 
 // a run of narrow levels in ONE workgroup of 1024 threads, a barrier between steps.  The tail of a sparse LU factor
@@ -162,13 +164,14 @@ struct TriFactor {                 // one triangular factor, rows in level order
     DevBuf<int64_t> rowptr; DevBuf<int> col; DevBuf<cplx> val; DevBuf<int> rowid; DevBuf<cplx> invd; DevBuf<int> lvlptr;
     std::vector<int> h_lvlptr;     // host copy of the level boundaries
     int nlevels = 0;
-    struct Seg { bool chain; int l0, l1; };       // launch schedule: a wide level [l0, l0 + 1) or a run of groups [l0, l1)
+    struct Seg { bool chain; int l0, l1; int lpr; };   // launch schedule: one level [l0, l0 + 1) as its own launch (lpr lanes per row) or a run of groups [l0, l1)
     std::vector<Seg> segs;
     DevBuf<int> grpptr, grpcnt, grpdense; DevBuf<cplx> dense;            // groups of the chain segments
     int ngroups = 0;
 };
 
-static constexpr int NARROW = 128;   // levels with at most this many rows are walked inside a single workgroup
+static constexpr int NARROW = 128;        // levels with at most this many rows ...
+static constexpr int64_t CHAIN_NNZ = 8192; // ... and at most this many entries are walked inside a single workgroup
 
 static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const int64_t* col, const double* val, bool lower) {
     // levels: depth of each row in the dependency graph of the triangular solve
@@ -200,13 +203,18 @@ static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const i
     std::vector<int> grpptr, grpcnt, grpdense;      // group -> first sorted row, rows, dense offset (-1: a single level)
     std::vector<int> group_of((size_t)N, -1);       // sorted row -> group, for the rows of multi-level groups only
     int64_t ndense = 0;
+    // a level is walked inside the single-workgroup chain only if it is narrow AND light (one CU streams it); a level
+    // with many rows or many entries gets its own launch over many CUs, a wave per row when the rows are long
+    std::vector<int64_t> lvlnnz((size_t)nlev, 0);
+    for (int64_t r = 0; r < N; ++r) lvlnnz[(size_t)level[(size_t)r]] += rowptr[r + 1] - rowptr[r] - 1;
+    auto chainable = [&](int l) { return lvlptr[(size_t)l + 1] - lvlptr[(size_t)l] <= NARROW && lvlnnz[(size_t)l] <= CHAIN_NNZ; };
     for (int l = 0; l < nlev;) {
         const int rows = lvlptr[(size_t)l + 1] - lvlptr[(size_t)l];
-        if (rows > NARROW) { F.segs.push_back({false, l, l + 1}); ++l; continue; }
+        if (!chainable(l)) { F.segs.push_back({false, l, l + 1, lvlnnz[(size_t)l] >= (int64_t)32 * rows ? 64 : 8}); ++l; continue; }
         const int gfirst = (int)grpptr.size();
-        while (l < nlev && lvlptr[(size_t)l + 1] - lvlptr[(size_t)l] <= NARROW) {
+        while (l < nlev && chainable(l)) {
             int e = l + 1, tot = lvlptr[(size_t)l + 1] - lvlptr[(size_t)l];
-            while (e < nlev && tot + (lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]) <= GROUP_ROWS) { tot += lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]; ++e; }
+            while (e < nlev && chainable(e) && tot + (lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]) <= GROUP_ROWS) { tot += lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]; ++e; }
             grpptr.push_back(lvlptr[(size_t)l]); grpcnt.push_back(tot);
             if (e > l + 1) {                        // several levels: rows coupled through a dense block
                 for (int k = lvlptr[(size_t)l]; k < lvlptr[(size_t)e]; ++k) group_of[(size_t)k] = (int)grpdense.size();
@@ -214,7 +222,7 @@ static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const i
             } else grpdense.push_back(-1);
             l = e;
         }
-        F.segs.push_back({true, gfirst, (int)grpptr.size()});
+        F.segs.push_back({true, gfirst, (int)grpptr.size(), 0});
     }
     LSFC_REQUIRE(ndense < ((int64_t)1 << 31), "preconditioner factor: too many dense blocks");
     // sorted CSR without the diagonal; entries coupling two rows of the same group go to that group's dense block
@@ -258,8 +266,12 @@ static void launch_factor(const TriFactor& F, const cplx* b, cplx* x, hipStream_
                                F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
         } else {
             const int first = F.h_lvlptr[(size_t)s.l0], nrows = F.h_lvlptr[(size_t)s.l0 + 1] - first;
-            hipLaunchKernelGGL(k_trsv_level, dim3((unsigned)(((int64_t)nrows * 8 + 255) / 256)), dim3(256), 0, st, first, nrows,
-                               F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
+            if (s.lpr == 64)
+                hipLaunchKernelGGL(k_trsv_level<64>, dim3((unsigned)(((int64_t)nrows * 64 + 255) / 256)), dim3(256), 0, st, first, nrows,
+                                   F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
+            else
+                hipLaunchKernelGGL(k_trsv_level<8>, dim3((unsigned)(((int64_t)nrows * 8 + 255) / 256)), dim3(256), 0, st, first, nrows,
+                                   F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
         }
     }
 }
