@@ -189,7 +189,9 @@ int lsfc_gmres(lsfc_plan* plan, double* x, const double* b, const lsfc_gmres_opt
  *     row_gather   k -> row of Msp that becomes row k of L U   (Julia: F.p .- 1;  NULL = identity)
  *     col_scatter  k -> column of Msp behind column k of L U   (Julia: F.q .- 1;  NULL = identity)
  *     row_scale    Rs (Julia: F.Rs), NULL = ones
- * As: CSR, 0-based, N rows.  All index arrays are int64_t. */
+ * As: CSR, 0-based, N rows.  All index arrays are int64_t.
+ * An lsfc_precond owns its work vectors: applies on one object are serialised by the stream they are enqueued on;
+ * do not apply the same object from two streams or threads at once. */
 typedef struct lsfc_precond lsfc_precond;
 int lsfc_precond_create(lsfc_precond** out, int64_t N,
                         const int64_t* As_rowptr, const int64_t* As_col, const double* As_val,
