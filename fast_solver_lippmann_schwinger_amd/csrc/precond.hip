@@ -83,6 +83,29 @@ __global__ void k_trsv_level(int first, int nrows, const int64_t* __restrict__ r
 // A group with dense offset -1 is a single level (independent rows).
 static constexpr int GROUP_ROWS = 16;
 
+// shared by the walking kernel and the heavy-group kernel: lanes i < nrows of ONE wave hold acc_i = b_i - (external sum);
+// forward substitution through the dense block, x_i written by lane i
+__device__ __forceinline__ void dense_resolve(int i, int nrows, int first, int dofs, double ax, double ay, const cplx* __restrict__ dense,
+                                              const int* __restrict__ rowid, const cplx* __restrict__ invd, cplx* x) {
+    const bool mine = i < nrows;
+    const cplx di = mine ? invd[first + i] : make_double2(0.0, 0.0);
+    cplx drow[GROUP_ROWS];
+#pragma unroll
+    for (int j = 0; j < GROUP_ROWS; ++j) drow[j] = (mine && j < i) ? dense[(int64_t)dofs + i * GROUP_ROWS + j] : make_double2(0.0, 0.0);
+    double myx = 0.0, myy = 0.0;
+#pragma unroll
+    for (int j = 0; j < GROUP_ROWS; ++j) {
+        if (j < nrows) {                                       // uniform
+            const double tx = ax * di.x - ay * di.y, ty = ax * di.y + ay * di.x;      // x_j on lane j
+            const double xjx = __shfl(tx, j, 64), xjy = __shfl(ty, j, 64);
+            if (i == j) { myx = xjx; myy = xjy; }
+            ax -= drow[j].x * xjx - drow[j].y * xjy; ay -= drow[j].x * xjy + drow[j].y * xjx;
+        }
+    }
+    if (mine) x[rowid[first + i]] = make_double2(myx, myy);
+}
+
+
 __global__ __launch_bounds__(1024)
 void k_trsv_chain(int g0, int g1, const int* __restrict__ grpptr, const int* __restrict__ grpcnt, const int* __restrict__ grpdense,
                   const cplx* __restrict__ dense,
@@ -126,32 +149,47 @@ void k_trsv_chain(int g0, int g1, const int* __restrict__ grpptr, const int* __r
         } else {                                                           // rows coupled through the dense block
             if (active && lane == 0) { const int row = rowid[k]; rx[g] = b[row].x - sx; ry[g] = b[row].y - sy; }
             __syncthreads();
-            if (wave == 0) {
-                const int i = tid;                                         // local row
-                const bool mine = i < nrows;
-                double ax = mine ? rx[i] : 0.0, ay = mine ? ry[i] : 0.0;
-                const cplx di = mine ? invd[first + i] : make_double2(0.0, 0.0);
-                cplx drow[GROUP_ROWS];
-#pragma unroll
-                for (int j = 0; j < GROUP_ROWS; ++j) drow[j] = (mine && j < i) ? dense[(int64_t)dofs + i * GROUP_ROWS + j] : make_double2(0.0, 0.0);
-                double myx = 0.0, myy = 0.0;
-#pragma unroll
-                for (int j = 0; j < GROUP_ROWS; ++j) {
-                    if (j < nrows) {                                       // uniform
-                        const double tx = ax * di.x - ay * di.y, ty = ax * di.y + ay * di.x;      // x_j on lane j
-                        const double xjx = __shfl(tx, j, 64), xjy = __shfl(ty, j, 64);
-                        if (i == j) { myx = xjx; myy = xjy; }
-                        ax -= drow[j].x * xjx - drow[j].y * xjy; ay -= drow[j].x * xjy + drow[j].y * xjx;
-                    }
-                }
-                if (mine) x[rowid[first + i]] = make_double2(myx, myy);
-            }
+            if (wave == 0) dense_resolve(tid, nrows, first, dofs, tid < nrows ? rx[tid] : 0.0, tid < nrows ? ry[tid] : 0.0, dense, rowid, invd, x);
         }
         __syncthreads();                          // this step's rows are visible to the next step (same workgroup)
     }
 }
 // (tried: loading the descriptor and first matrix entry of the next step while the current one is reduced -- slower:
 // the walk is bound by the barrier / reduction chain, not by those loads)
+
+// A HEAVY group (<= 16 coupled rows with more entries than one CU should stream) as two launches:
+//   k_trsv_group_ext   one 512-thread workgroup per row sums the row's external entries (many CUs, whole rows in flight)
+//   k_trsv_group_dense one wave resolves the dense coupling block from those sums and writes x
+__global__ __launch_bounds__(512)
+void k_trsv_group_ext(int first, const int64_t* __restrict__ rowptr, const int* __restrict__ col, const cplx* __restrict__ val,
+                      const int* __restrict__ rowid, const cplx* __restrict__ b, const cplx* __restrict__ x, cplx* __restrict__ gacc) {
+    __shared__ double psx[8], psy[8];
+    const int k = first + blockIdx.x, tid = threadIdx.x;
+    double sx = 0.0, sy = 0.0;
+    const int64_t e1 = rowptr[k + 1];
+#pragma unroll 4
+    for (int64_t e = rowptr[k] + tid; e < e1; e += 512) {
+        const cplx a = val[e], v = x[col[e]];
+        sx += a.x * v.x - a.y * v.y; sy += a.x * v.y + a.y * v.x;
+    }
+    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
+    if ((tid & 63) == 0) { psx[tid >> 6] = sx; psy[tid >> 6] = sy; }
+    __syncthreads();
+    if (tid == 0) {
+        sx = 0.0; sy = 0.0;
+        for (int w = 0; w < 8; ++w) { sx += psx[w]; sy += psy[w]; }
+        const int row = rowid[k];
+        gacc[blockIdx.x] = make_double2(b[row].x - sx, b[row].y - sy);
+    }
+}
+
+__global__ __launch_bounds__(64)
+void k_trsv_group_dense(int first, int nrows, int dofs, const cplx* __restrict__ dense, const int* __restrict__ rowid,
+                        const cplx* __restrict__ invd, const cplx* __restrict__ gacc, cplx* x) {
+    const int i = threadIdx.x;
+    const cplx a = i < nrows ? gacc[i] : make_double2(0.0, 0.0);
+    dense_resolve(i, nrows, first, dofs, a.x, a.y, dense, rowid, invd, x);
+}
 
 __global__ void k_scatter(const cplx* __restrict__ w, const int* __restrict__ dst, cplx* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,9 +202,13 @@ struct TriFactor {                 // one triangular factor, rows in level order
     DevBuf<int64_t> rowptr; DevBuf<int> col; DevBuf<cplx> val; DevBuf<int> rowid; DevBuf<cplx> invd; DevBuf<int> lvlptr;
     std::vector<int> h_lvlptr;     // host copy of the level boundaries
     int nlevels = 0;
-    struct Seg { bool chain; int l0, l1; int lpr; };   // launch schedule: one level [l0, l0 + 1) as its own launch (lpr lanes per row) or a run of groups [l0, l1)
+    // launch schedule: kind 0 one level [l0, l0 + 1) as its own launch (lpr lanes per row); 1 a run of groups [l0, l1) walked by
+    // one workgroup; 2 the heavy group l0 as two launches
+    struct Seg { int kind; int l0, l1; int lpr; };
     std::vector<Seg> segs;
     DevBuf<int> grpptr, grpcnt, grpdense; DevBuf<cplx> dense;            // groups of the chain segments
+    std::vector<int> h_grpptr, h_grpcnt, h_grpdense;
+    DevBuf<cplx> gacc;                                                   // b - external sums of a heavy group
     int ngroups = 0;
 };
 
@@ -210,19 +252,28 @@ static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const i
     auto chainable = [&](int l) { return lvlptr[(size_t)l + 1] - lvlptr[(size_t)l] <= NARROW && lvlnnz[(size_t)l] <= CHAIN_NNZ; };
     for (int l = 0; l < nlev;) {
         const int rows = lvlptr[(size_t)l + 1] - lvlptr[(size_t)l];
-        if (!chainable(l)) { F.segs.push_back({false, l, l + 1, lvlnnz[(size_t)l] >= (int64_t)32 * rows ? 64 : 8}); ++l; continue; }
-        const int gfirst = (int)grpptr.size();
+        if (!chainable(l)) { F.segs.push_back({0, l, l + 1, lvlnnz[(size_t)l] >= (int64_t)32 * rows ? 64 : 8}); ++l; continue; }
+        int gfirst = (int)grpptr.size();
         while (l < nlev && chainable(l)) {
             int e = l + 1, tot = lvlptr[(size_t)l + 1] - lvlptr[(size_t)l];
-            while (e < nlev && chainable(e) && tot + (lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]) <= GROUP_ROWS) { tot += lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]; ++e; }
+            int64_t gnnz = lvlnnz[(size_t)l];
+            while (e < nlev && chainable(e) && tot + (lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]) <= GROUP_ROWS) {
+                tot += lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]; gnnz += lvlnnz[(size_t)e]; ++e;
+            }
             grpptr.push_back(lvlptr[(size_t)l]); grpcnt.push_back(tot);
             if (e > l + 1) {                        // several levels: rows coupled through a dense block
                 for (int k = lvlptr[(size_t)l]; k < lvlptr[(size_t)e]; ++k) group_of[(size_t)k] = (int)grpdense.size();
                 grpdense.push_back((int)ndense); ndense += GROUP_ROWS * GROUP_ROWS;
+                if (gnnz > CHAIN_NNZ) {             // too much for one CU: its own pair of launches, the walk resumes after it
+                    const int gi = (int)grpptr.size() - 1;
+                    if (gi > gfirst) F.segs.push_back({1, gfirst, gi, 0});
+                    F.segs.push_back({2, gi, gi + 1, 0});
+                    gfirst = gi + 1;
+                }
             } else grpdense.push_back(-1);
             l = e;
         }
-        F.segs.push_back({true, gfirst, (int)grpptr.size(), 0});
+        if ((int)grpptr.size() > gfirst) F.segs.push_back({1, gfirst, (int)grpptr.size(), 0});
     }
     LSFC_REQUIRE(ndense < ((int64_t)1 << 31), "preconditioner factor: too many dense blocks");
     // sorted CSR without the diagonal; entries coupling two rows of the same group go to that group's dense block
@@ -256,14 +307,20 @@ static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const i
     };
     up(F.rowptr, rp); up(F.col, cc); up(F.val, vv); up(F.rowid, order); up(F.invd, invd); up(F.lvlptr, lvlptr);
     up(F.grpptr, grpptr); up(F.grpcnt, grpcnt); up(F.grpdense, grpdense); up(F.dense, dense);
+    F.h_grpptr = grpptr; F.h_grpcnt = grpcnt; F.h_grpdense = grpdense;
+    F.gacc.alloc(GROUP_ROWS);
     F.h_lvlptr = lvlptr; F.nlevels = nlev; F.ngroups = (int)grpdense.size();
 }
 
 static void launch_factor(const TriFactor& F, const cplx* b, cplx* x, hipStream_t st) {
     for (const auto& s : F.segs) {
-        if (s.chain) {
+        if (s.kind == 1) {
             hipLaunchKernelGGL(k_trsv_chain, dim3(1), dim3(1024), 0, st, s.l0, s.l1, F.grpptr.p, F.grpcnt.p, F.grpdense.p, F.dense.p,
                                F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
+        } else if (s.kind == 2) {
+            const int first = F.h_grpptr[(size_t)s.l0], nrows = F.h_grpcnt[(size_t)s.l0], dofs = F.h_grpdense[(size_t)s.l0];
+            hipLaunchKernelGGL(k_trsv_group_ext, dim3((unsigned)nrows), dim3(512), 0, st, first, F.rowptr.p, F.col.p, F.val.p, F.rowid.p, b, x, F.gacc.p);
+            hipLaunchKernelGGL(k_trsv_group_dense, dim3(1), dim3(64), 0, st, first, nrows, dofs, F.dense.p, F.rowid.p, F.invd.p, F.gacc.p, x);
         } else {
             const int first = F.h_lvlptr[(size_t)s.l0], nrows = F.h_lvlptr[(size_t)s.l0 + 1] - first;
             if (s.lpr == 64)
@@ -306,6 +363,14 @@ static void enqueue_all(lsfc_precond* pc, hipStream_t st) {
 static void precond_apply_dev(lsfc_precond* pc, cplx* v, hipStream_t st) {
     const size_t bytes = (size_t)pc->N * sizeof(cplx);
     LSFC_HIP(hipMemcpyAsync(pc->vin.p, v, bytes, hipMemcpyDeviceToDevice, st));
+    // LSFC_PRECOND_GRAPH=0 (developer switch): plain stream launches instead of the captured graph
+    static const bool no_graph = getenv("LSFC_PRECOND_GRAPH") && getenv("LSFC_PRECOND_GRAPH")[0] == '0';
+    if (no_graph) {
+        enqueue_all(pc, st);
+        LSFC_HIP(hipGetLastError());
+        LSFC_HIP(hipMemcpyAsync(v, pc->vout.p, bytes, hipMemcpyDeviceToDevice, st));
+        return;
+    }
     if (!pc->exec) {
         // capture the fixed sequence once (internal buffers only), then replay it
         hipStream_t cs; LSFC_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -371,7 +436,8 @@ int lsfc_precond_create(lsfc_precond** out, int64_t N,
         build_factor(pc->L, N, L_rowptr, L_col, L_val, true);
         build_factor(pc->U, N, U_rowptr, U_col, U_val, false);
         for (DevBuf<cplx>* b : { &pc->vin, &pc->y0, &pc->z, &pc->w, &pc->vout }) { b->alloc((size_t)N); LSFC_HIP(hipMemset(b->p, 0, b->bytes())); }
-        pc->launches = 2 + (int)pc->L.segs.size() + (int)pc->U.segs.size();
+        pc->launches = 2;
+        for (const TriFactor* F : { &pc->L, &pc->U }) for (const auto& sg : F->segs) pc->launches += sg.kind == 2 ? 2 : 1;
         *out = pc.release();
     });
 }
