@@ -198,6 +198,14 @@ def main():
                       "parallelism": "single GPU" if world == 1 else f"z-slabs over {world} GPUs, 2 RCCL all-to-all per apply"},
            "achieved_algorithmic_GBps_per_gpu": whole / world, "hbm_roofline_frac_whole_apply": whole / world / HBM_PEAK_GBPS,
            "roofline": roofline}
+    if world > 1:
+        # the two slab transposes of an apply move 2 * 2N complex in total; rank p sends 2N*16 B*(P-1)/P^2 per transpose
+        # over its P-1 direct xGMI links (one link per GPU pair).  A model, not a measurement: see DESIGN.md section 5.
+        per_link = 2 * (2.0 * N * 16.0) / world ** 2
+        out["link_model"] = {"bytes_per_link_per_direction_per_apply": per_link,
+                             "ms_at_76.8_GBps_per_direction": per_link / 76.8e9 * 1e3,
+                             "note": "xGMI time floor of the two all-to-all transposes at the nominal per-direction link rate; "
+                                     "the apply cannot be faster than this however well it overlaps"}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
