@@ -91,3 +91,32 @@ def test_delta_response_shift_invariance_n512(lsfc, op512):
     # the kernel is even: response at src + p equals response at src - p
     c = ra[a[2] - 50:a[2] + 51, a[1] - 50:a[1] + 51, a[0] - 50:a[0] + 51]
     assert float(torch.linalg.norm(c - torch.flip(c, dims=(0, 1, 2))) / torch.linalg.norm(c)) < 1e-12
+
+
+@pytest.mark.parametrize("n", [320, 384])
+def test_analytic_gaussian_mixed_radix_cubes(lsfc, n):
+    # the same known answer on large cubes whose working grid is a mixed-radix one (640 = 5*2^7, 768 = 3*2^8): symbol
+    # generator, mixed-radix passes and half symbols at full size.  (Cubes only: the reference's builder takes the
+    # frequency lattice of every axis from the x extent, src/FastConvolution3D.jl:72-81, which is the physical kernel
+    # only when the three axes have the same length.)
+    import torch
+    h = 1.0 / n
+    x = -0.5 + h * np.arange(n)
+    k, sig = 12.0, 0.05
+    M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, k, np.zeros(n ** 3))
+    assert M.pipeline == "pruned-hip" and M.padded_dims == (2 * n, 2 * n, 2 * n)
+    gx = torch.from_numpy(np.exp(-x ** 2 / (2 * sig ** 2))).cuda()
+    f = ((gx[:, None, None] * gx[None, :, None] * gx[None, None, :]) / ((2 * np.pi) ** 1.5 * sig ** 3)).to(torch.complex128).reshape(-1)
+    u = lsfc.FFTconvolution(M, f)
+    M.synchronize()
+    uv = u.view(n, n, n)                                    # [z][y][x]
+    X2, Y2 = np.meshgrid(x, x, indexing="ij")
+    worst = 0.0
+    for kz in [0, 77, n // 2, n - 1]:
+        got = uv[kz].cpu().numpy().T                        # [x][y]
+        with np.errstate(all="ignore"):
+            ref = -o.sol_ref_helmholtz(X2, Y2, np.full_like(X2, x[kz]), sig, k)
+        ok = np.isfinite(ref)
+        worst = max(worst, float(np.linalg.norm((got - ref)[ok]) / np.linalg.norm(ref[ok])))
+    M.close()
+    assert worst < 1e-10, worst
