@@ -96,7 +96,10 @@ int lsfc_plan_create_trap2d(lsfc_plan** out, int64_t n, int64_t m, double x0, do
 /* Replaces buildFastConvolution3D(x,y,z,X,Y,Z,h,k,nu) (src/FastConvolution3D.jl:68-101
  * + Gtruncated3D, src/Functions.jl:49-51).  The (4n)^3 symbol cube of the
  * reference (137 GB at n=512) is never materialised: the symbol is evaluated
- * slab-wise on the device and reduced to the equivalent (2n)^3 grid. */
+ * slab-wise on the device and reduced to the equivalent (2n)^3 grid.
+ * box = |x[end] - x[1]| + h: as in the reference (:72-81), the truncation radius and the frequency lattice of ALL three
+ * axes derive from the x extent, so the symbol is the physical truncated kernel only when n == m == l (the reference's
+ * own use); for other shapes the reference's arithmetic is reproduced as it is. */
 int lsfc_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega,
                           const double* nu, unsigned flags, int device);
 
