@@ -105,8 +105,7 @@ void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
     LSFC_REQUIRE(!d->sim, "simulated ranks are driven through lsfc_dist_sim_apply");
     hipStream_t st = p->stream;
     // LSFC_DIST_OVERLAP=0: no overlap -- every exchange on the compute stream, chunk after chunk (debugging aid)
-    static const bool no_overlap = getenv("LSFC_DIST_OVERLAP") && getenv("LSFC_DIST_OVERLAP")[0] == '0';
-    if ((d->nranks == 1 && !d->force_overlap) || no_overlap) {
+    if ((d->nranks == 1 && !d->force_overlap) || d->no_overlap) {
         phase1(p, x, use_nu, st);
         for (int c = 0; c < d->K; ++c) { exchange(p, c, false, st); phase2(p, c, st); exchange(p, c, true, st); }
         phase3(p, x, y, alpha, beta, st);
@@ -116,8 +115,7 @@ void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
     // all-to-all back of chunk c-1 (stream cs2, second communicator) run while chunk c is transformed (stream st).
     // The two ends of the pipeline are split once more over the z halves of the own slab, so that the first exchange
     // starts after half of the x pass and the second half of the last exchange back hides half of the inverse x pass.
-    const bool no_edges = getenv("LSFC_DIST_SPLIT_EDGES") && getenv("LSFC_DIST_SPLIT_EDGES")[0] == '0';
-    const bool edges = !no_edges && d->lz % 2 == 0;
+    const bool edges = d->split_edges && d->lz % 2 == 0;
     const int K = d->K;
     if (edges) {
         phase1(p, x, use_nu, st, 0);
@@ -215,6 +213,9 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     d->K = K; d->Wc = d->W / K;
     // LSFC_DIST_FORCE_OVERLAP=1: run the three-stream pipeline even with one rank (tests of the event logic)
     d->force_overlap = getenv("LSFC_DIST_FORCE_OVERLAP") && getenv("LSFC_DIST_FORCE_OVERLAP")[0] == '1';
+    // LSFC_DIST_OVERLAP=0: every exchange on the compute stream; LSFC_DIST_SPLIT_EDGES=0: no z-half split of the pipeline ends
+    d->no_overlap = getenv("LSFC_DIST_OVERLAP") && getenv("LSFC_DIST_OVERLAP")[0] == '0';
+    d->split_edges = !(getenv("LSFC_DIST_SPLIT_EDGES") && getenv("LSFC_DIST_SPLIT_EDGES")[0] == '0');
     // LSFC_DIST_FORCE_COMM=1: build the communicators and route the (self) exchange through RCCL even with one rank
     d->force_comm = !sim && getenv("LSFC_DIST_FORCE_COMM") && getenv("LSFC_DIST_FORCE_COMM")[0] == '1';
     if (!sim && (nranks > 1 || d->force_comm)) {

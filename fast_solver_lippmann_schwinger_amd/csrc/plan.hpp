@@ -48,6 +48,7 @@ struct GmresWorkspace {
 struct DistState {
     int rank = 0, nranks = 1;
     bool force_overlap = false, force_comm = false;
+    bool no_overlap = false, split_edges = true;     // LSFC_DIST_OVERLAP=0 / LSFC_DIST_SPLIT_EDGES=0, read at plan creation
     bool sim = false;        // simulated ranks in one process (tests): exchanges done by lsfc_dist_sim_apply
     void* comm = nullptr;    // ncclComm_t
     void* comm2 = nullptr;   // second communicator: the way back runs on its own stream, concurrently with the way in
