@@ -31,7 +31,10 @@ def _alltoall_blocks(send_blocks, rank, world):
     return [g.numpy().view(np.complex128).reshape(np.stack(send_blocks).shape)[rank] for g in gathered]
 
 
-def _worker(rank, world, port, n, m, l, k, q):
+def _worker(rank, world, port, n, m, l, k, q, K=1, halves=False):
+    """K: pipeline chunks of the owned x' range (csrc/dist.hip: S1 is [dest rank][chunk][Wc][m][lz], block index
+    dest * K + chunk; R1 is [chunk][slot = source rank][Wc][m][lz]).  halves: every message is shipped as the two z
+    halves of its block, as the split pipeline ends do (blocks are z-slowest, so a z half is a contiguous half)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -41,23 +44,41 @@ def _worker(rank, world, port, n, m, l, k, q):
         b = rng.standard_normal(n * m * l) + 1j * rng.standard_normal(n * m * l)
         lo, hi = slab_range(l, rank, world)
         lz, Lx, W = hi - lo, 2 * n, 2 * n // world
+        Wc = W // K
+        B = Wc * m * lz                                          # elements of one (rank, chunk) block
         xl = (nu * b).reshape((n, m, l), order="F")[:, :, lo:hi]
-        # phase 1: x pass on own planes, written packed per destination rank
+        # phase 1: x pass on own planes, written packed per (destination rank, chunk): storage index s -> block s // Wc
         A = np.fft.fft(np.concatenate([xl, np.zeros_like(xl)], axis=0), axis=0)            # [Lx][m][lz]
-        S1 = [A[qd * W:(qd + 1) * W].reshape(-1, order="F") for qd in range(world)]         # block q = [W][m][lz]
-        # exchange 1; fact (1): concatenation of the received blocks is the natural [W][m][l]
-        R1 = np.concatenate(_alltoall_blocks(S1, rank, world)).reshape((W, m, l), order="F")
-        # phase 2 on the owned x' range
-        B = np.fft.fft(np.concatenate([R1, np.zeros_like(R1)], axis=1), axis=1)
-        B = np.fft.fft(np.concatenate([B, np.zeros((W, 2 * m, l), complex)], axis=2), axis=2)
-        B = B * G2[rank * W:(rank + 1) * W]
-        B = np.fft.ifft(B, axis=2)[:, :, :l]
-        B = np.fft.ifft(B, axis=1)[:, :m, :]
-        # exchange 2; fact (2): block p of the flat natural array is rank p's z range
-        flat = B.reshape(-1, order="F")
-        blk = W * m * lz
-        back = _alltoall_blocks([flat[p * blk:(p + 1) * blk] for p in range(world)], rank, world)
-        full = np.concatenate([bb.reshape((W, m, lz), order="F") for bb in back], axis=0)    # [Lx][m][lz]
+        S1 = np.concatenate([A[blk * Wc:(blk + 1) * Wc].reshape(-1, order="F") for blk in range(world * K)])
+
+        def ship(buf_blocks):
+            """all-to-all of one block per destination; with `halves`, as two messages per block"""
+            if not halves:
+                return _alltoall_blocks(buf_blocks, rank, world)
+            h = buf_blocks[0].size // 2
+            lo_half = _alltoall_blocks([x[:h] for x in buf_blocks], rank, world)
+            hi_half = _alltoall_blocks([x[h:] for x in buf_blocks], rank, world)
+            return [np.concatenate([a, c]) for a, c in zip(lo_half, hi_half)]
+
+        full_chunks = []
+        for c in range(K):
+            # exchange of chunk c: block (q * K + c) of S1 -> rank q; fact (1): the received blocks, in source-rank
+            # order, concatenate to the natural [Wc][m][l] of this chunk's x' range
+            got = ship([S1[(qd * K + c) * B:(qd * K + c + 1) * B] for qd in range(world)])
+            R1 = np.concatenate(got).reshape((Wc, m, l), order="F")
+            # phase 2 on the chunk's x' range (storage = natural order in this numpy model)
+            xs = (rank * K + c) * Wc
+            Bc = np.fft.fft(np.concatenate([R1, np.zeros_like(R1)], axis=1), axis=1)
+            Bc = np.fft.fft(np.concatenate([Bc, np.zeros((Wc, 2 * m, l), complex)], axis=2), axis=2)
+            Bc = Bc * G2[xs:xs + Wc]
+            Bc = np.fft.ifft(Bc, axis=2)[:, :, :l]
+            Bc = np.fft.ifft(Bc, axis=1)[:, :m, :]
+            # exchange back; fact (2): slot p of the flat natural array of the chunk is rank p's z range
+            flat = Bc.reshape(-1, order="F")
+            back = ship([flat[p * B:(p + 1) * B] for p in range(world)])
+            full_chunks.append(back)                             # back[src] = block (src * K + c) of S1
+        # S1 layout on the way back: [source rank][chunk][Wc][m][lz] -> x' index (src * K + c) * Wc
+        full = np.concatenate([full_chunks[c][src].reshape((Wc, m, lz), order="F") for src in range(world) for c in range(K)], axis=0)
         yl = b.reshape((n, m, l), order="F")[:, :, lo:hi] + k**2 * np.fft.ifft(full, axis=0)[:n]
         ref = o.apply_reduced(G2, nu, k, b, (n, m, l)).reshape((n, m, l), order="F")[:, :, lo:hi]
         q.put((rank, float(np.linalg.norm(yl - ref) / np.linalg.norm(ref))))
@@ -65,13 +86,13 @@ def _worker(rank, world, port, n, m, l, k, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dims", [(8, 4, 6), (16, 16, 16)])
-def test_slab_decomposition_world2_gloo(dims):
+@pytest.mark.parametrize("dims,K,halves", [((8, 4, 6), 1, False), ((16, 16, 16), 1, False), ((16, 8, 12), 2, False), ((16, 8, 12), 4, True)])
+def test_slab_decomposition_world2_gloo(dims, K, halves):
     n, m, l = dims
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, m, l, 3.0, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, m, l, 3.0, q, K, halves)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(2))
