@@ -138,3 +138,18 @@ def test_golden_3d(name):
     c = cases.case_3d(name)
     g = np.load(os.path.join(GOLD, f"3d_{name}.npz"))
     assert rel_err(o.mul(c["M"], c["b"]), g["apply_random"]) < 1e-13
+
+
+def test_sparsifying_preconditioner_restatement_is_the_dense_formula():
+    # src/preconditioner.jl:132-145: P \ b == lu(Msp) \ (As * b); the oracle's sparse-LU restatement against dense algebra
+    n = 9
+    x, h = cases.grid(n, True)
+    X, Y = o.grid2d(x, x)
+    Msp, As = cases.sparsifying_pair_2d(n, h, 0.5 / h, o.gaussian_bump(X, Y))
+    P = o.SparsifyingPreconditioner(Msp, As)
+    b = o.random_vector(n * n)
+    ref = np.linalg.solve(Msp.toarray(), As.toarray() @ b)
+    assert rel_err(P.solve(b), ref) < 1e-12
+    v = b.copy()
+    P.ldiv_(v)                                    # two-argument in-place form, :147-170
+    assert rel_err(v, ref) < 1e-12
