@@ -191,6 +191,68 @@ void k_trsv_group_dense(int first, int nrows, int dofs, const cplx* __restrict__
     dense_resolve(i, nrows, first, dofs, a.x, a.y, dense, rowid, invd, x);
 }
 
+// A dense RUN: a long sequence of consecutive thin levels (the trailing separator block of a sparse LU factor is a
+// chain of one-row levels, each row coupled to almost all rows before it).  Its R rows are solved as a dense
+// lower-triangular system in blocks of 64, right-looking:
+//   k_run_ext     acc_i = b_i - (entries outside the run), one workgroup per row                       1 launch
+//   k_run_diag    one wave solves the 64 x 64 diagonal block J from acc (block staged in LDS)          R / 64 launches
+//   k_run_update  acc_i -= D[i, block J] x_J for the rows below, one wave per row, many CUs            R / 64 - 1 launches
+// The coupling D is stored dense (R x R, row-major), taken out of the CSR rows at set-up.
+static constexpr int RUN_BLOCK = 64;
+
+__global__ __launch_bounds__(256)
+void k_run_ext(int first, const int64_t* __restrict__ rowptr, const int* __restrict__ col, const cplx* __restrict__ val,
+               const int* __restrict__ rowid, const cplx* __restrict__ b, const cplx* __restrict__ x, cplx* __restrict__ racc) {
+    __shared__ double psx[4], psy[4];
+    const int k = first + blockIdx.x, tid = threadIdx.x;
+    double sx = 0.0, sy = 0.0;
+    const int64_t e1 = rowptr[k + 1];
+#pragma unroll 4
+    for (int64_t e = rowptr[k] + tid; e < e1; e += 256) {
+        const cplx a = val[e], v = x[col[e]];
+        sx += a.x * v.x - a.y * v.y; sy += a.x * v.y + a.y * v.x;
+    }
+    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
+    if ((tid & 63) == 0) { psx[tid >> 6] = sx; psy[tid >> 6] = sy; }
+    __syncthreads();
+    if (tid == 0) {
+        const int row = rowid[k];
+        racc[blockIdx.x] = make_double2(b[row].x - (psx[0] + psx[1] + psx[2] + psx[3]), b[row].y - (psy[0] + psy[1] + psy[2] + psy[3]));
+    }
+}
+
+__global__ __launch_bounds__(64)
+void k_run_diag(int first, int R, int J, const cplx* __restrict__ D, const int* __restrict__ rowid, const cplx* __restrict__ invd,
+                const cplx* __restrict__ racc, cplx* __restrict__ rx, cplx* x) {
+    __shared__ cplx blk[RUN_BLOCK][RUN_BLOCK + 1];
+    const int lane = threadIdx.x, r0 = J * RUN_BLOCK;
+    const int nb = R - r0 < RUN_BLOCK ? R - r0 : RUN_BLOCK;
+    for (int r = 0; r < nb; ++r) if (lane < nb) blk[r][lane] = D[(int64_t)(r0 + r) * R + r0 + lane];   // row r, coalesced
+    __syncthreads();
+    const bool mine = lane < nb;
+    cplx acc = mine ? racc[r0 + lane] : make_double2(0.0, 0.0);
+    const cplx di = mine ? invd[first + r0 + lane] : make_double2(0.0, 0.0);
+    double myx = 0.0, myy = 0.0;
+    for (int j = 0; j < nb; ++j) {
+        const double tx = acc.x * di.x - acc.y * di.y, ty = acc.x * di.y + acc.y * di.x;                  // x_j on lane j
+        const double xjx = __shfl(tx, j, 64), xjy = __shfl(ty, j, 64);
+        if (lane == j) { myx = xjx; myy = xjy; }
+        if (mine && lane > j) { const cplx d = blk[lane][j]; acc.x -= d.x * xjx - d.y * xjy; acc.y -= d.x * xjy + d.y * xjx; }
+    }
+    if (mine) { const cplx v = make_double2(myx, myy); rx[r0 + lane] = v; x[rowid[first + r0 + lane]] = v; }
+}
+
+__global__ __launch_bounds__(256)
+void k_run_update(int R, int J, const cplx* __restrict__ D, const cplx* __restrict__ rx, cplx* __restrict__ racc) {
+    const int lane = threadIdx.x & 63, r0 = J * RUN_BLOCK;
+    const int i = r0 + RUN_BLOCK + (int)blockIdx.x * 4 + (threadIdx.x >> 6);          // a wave per row below block J
+    if (i >= R) return;                                                               // (whole waves leave together)
+    const cplx d = D[(int64_t)i * R + r0 + lane], v = rx[r0 + lane];                  // block J is a full block here
+    double sx = d.x * v.x - d.y * v.y, sy = d.x * v.y + d.y * v.x;
+    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
+    if (lane == 0) { cplx a = racc[i]; a.x -= sx; a.y -= sy; racc[i] = a; }
+}
+
 __global__ void k_scatter(const cplx* __restrict__ w, const int* __restrict__ dst, cplx* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[dst[i]] = w[i];
@@ -203,17 +265,23 @@ struct TriFactor {                 // one triangular factor, rows in level order
     std::vector<int> h_lvlptr;     // host copy of the level boundaries
     int nlevels = 0;
     // launch schedule: kind 0 one level [l0, l0 + 1) as its own launch (lpr lanes per row); 1 a run of groups [l0, l1) walked by
-    // one workgroup; 2 the heavy group l0 as two launches
+    // one workgroup; 2 the heavy group l0 as two launches; 3 the dense run l0
     struct Seg { int kind; int l0, l1; int lpr; };
     std::vector<Seg> segs;
     DevBuf<int> grpptr, grpcnt, grpdense; DevBuf<cplx> dense;            // groups of the chain segments
     std::vector<int> h_grpptr, h_grpcnt, h_grpdense;
     DevBuf<cplx> gacc;                                                   // b - external sums of a heavy group
+    struct Run { int first, R; int64_t dofs; };                         // dense runs: first sorted row, rows, offset of the R x R block
+    std::vector<Run> runs;
+    DevBuf<cplx> rdense, racc, rx;
     int ngroups = 0;
 };
 
 static constexpr int NARROW = 128;        // levels with at most this many rows ...
 static constexpr int64_t CHAIN_NNZ = 8192; // ... and at most this many entries are walked inside a single workgroup
+static constexpr int RUN_THIN = 4;        // dense runs: consecutive levels of at most this many rows ...
+static constexpr int RUN_MIN = 96;        // ... totalling at least this many rows, cut into pieces of at most
+static constexpr int RUN_MAX = 1024;      // this many rows (R x R dense block: 16 MB)
 
 static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const int64_t* col, const double* val, bool lower) {
     // levels: depth of each row in the dependency graph of the triangular solve
@@ -249,10 +317,37 @@ static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const i
     // with many rows or many entries gets its own launch over many CUs, a wave per row when the rows are long
     std::vector<int64_t> lvlnnz((size_t)nlev, 0);
     for (int64_t r = 0; r < N; ++r) lvlnnz[(size_t)level[(size_t)r]] += rowptr[r + 1] - rowptr[r] - 1;
-    auto chainable = [&](int l) { return lvlptr[(size_t)l + 1] - lvlptr[(size_t)l] <= NARROW && lvlnnz[(size_t)l] <= CHAIN_NNZ; };
+    // dense runs: long sequences of consecutive thin levels (trailing separator blocks), cut into pieces of <= RUN_MAX rows
+    std::vector<int> run_of_level((size_t)nlev, -1), run_of((size_t)N, -1);
+    int64_t nrdense = 0;
+    for (int l = 0; l < nlev;) {
+        int e = l, rows = 0;
+        while (e < nlev && lvlptr[(size_t)e + 1] - lvlptr[(size_t)e] <= RUN_THIN) { rows += lvlptr[(size_t)e + 1] - lvlptr[(size_t)e]; ++e; }
+        if (rows < RUN_MIN) { l = e > l ? e : l + 1; continue; }
+        while (l < e) {                             // pieces end at level boundaries
+            int pe = l, prow = 0;
+            while (pe < e && prow + (lvlptr[(size_t)pe + 1] - lvlptr[(size_t)pe]) <= RUN_MAX) { prow += lvlptr[(size_t)pe + 1] - lvlptr[(size_t)pe]; ++pe; }
+            const int ri = (int)F.runs.size();
+            F.runs.push_back({lvlptr[(size_t)l], prow, nrdense});
+            nrdense += (int64_t)prow * prow;
+            for (int q = l; q < pe; ++q) run_of_level[(size_t)q] = ri;
+            for (int k = lvlptr[(size_t)l]; k < lvlptr[(size_t)pe]; ++k) run_of[(size_t)k] = ri;
+            l = pe;
+        }
+    }
+    auto chainable = [&](int l) { return run_of_level[(size_t)l] < 0 && lvlptr[(size_t)l + 1] - lvlptr[(size_t)l] <= NARROW && lvlnnz[(size_t)l] <= CHAIN_NNZ; };
     for (int l = 0; l < nlev;) {
         const int rows = lvlptr[(size_t)l + 1] - lvlptr[(size_t)l];
-        if (!chainable(l)) { F.segs.push_back({0, l, l + 1, lvlnnz[(size_t)l] >= (int64_t)32 * rows ? 64 : 8}); ++l; continue; }
+        if (run_of_level[(size_t)l] >= 0) {         // a dense run: its own sequence of launches
+            const int ri = run_of_level[(size_t)l];
+            F.segs.push_back({3, ri, ri + 1, 0});
+            while (l < nlev && run_of_level[(size_t)l] == ri) ++l;
+            continue;
+        }
+        if (!chainable(l)) {                        // lanes per row ~ entries per row
+            const int64_t avg = lvlnnz[(size_t)l] / (rows > 0 ? rows : 1);
+            F.segs.push_back({0, l, l + 1, avg >= 48 ? 64 : (avg >= 24 ? 32 : (avg >= 12 ? 16 : 8))}); ++l; continue;
+        }
         int gfirst = (int)grpptr.size();
         while (l < nlev && chainable(l)) {
             int e = l + 1, tot = lvlptr[(size_t)l + 1] - lvlptr[(size_t)l];
@@ -279,7 +374,7 @@ static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const i
     // sorted CSR without the diagonal; entries coupling two rows of the same group go to that group's dense block
     std::vector<int> sorted_of((size_t)N);
     for (int64_t k = 0; k < N; ++k) sorted_of[(size_t)order[(size_t)k]] = (int)k;
-    std::vector<cplx> dense((size_t)ndense, make_double2(0.0, 0.0));
+    std::vector<cplx> dense((size_t)ndense, make_double2(0.0, 0.0)), rdense((size_t)nrdense, make_double2(0.0, 0.0));
     std::vector<int64_t> rp((size_t)N + 1, 0);
     std::vector<int> cc; std::vector<cplx> vv; std::vector<cplx> invd((size_t)N);
     cc.reserve((size_t)(rowptr[N])); vv.reserve((size_t)(rowptr[N]));
@@ -289,6 +384,13 @@ static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const i
         for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
             if (col[e] == r) continue;
             const int kc = sorted_of[(size_t)col[e]];
+            if (run_of[(size_t)k] >= 0 && run_of[(size_t)kc] == run_of[(size_t)k]) {
+                const TriFactor::Run& rn = F.runs[(size_t)run_of[(size_t)k]];
+                const int i = (int)k - rn.first, j = kc - rn.first;                             // local indices, j < i
+                LSFC_REQUIRE(j >= 0 && j < i && i < rn.R, "internal: run block index (%d, %d)", i, j);
+                rdense[(size_t)(rn.dofs + (int64_t)i * rn.R + j)] = make_double2(val[2 * e], val[2 * e + 1]);
+                continue;
+            }
             if (grp >= 0 && group_of[(size_t)kc] == grp) {
                 const int i = (int)k - grpptr[(size_t)grp], j = kc - grpptr[(size_t)grp];       // local indices, j < i
                 LSFC_REQUIRE(j >= 0 && j < i && i < GROUP_ROWS, "internal: dense block index (%d, %d)", i, j);
@@ -309,6 +411,7 @@ static void build_factor(TriFactor& F, int64_t N, const int64_t* rowptr, const i
     up(F.grpptr, grpptr); up(F.grpcnt, grpcnt); up(F.grpdense, grpdense); up(F.dense, dense);
     F.h_grpptr = grpptr; F.h_grpcnt = grpcnt; F.h_grpdense = grpdense;
     F.gacc.alloc(GROUP_ROWS);
+    up(F.rdense, rdense); F.racc.alloc(RUN_MAX); F.rx.alloc(RUN_MAX);
     F.h_lvlptr = lvlptr; F.nlevels = nlev; F.ngroups = (int)grpdense.size();
 }
 
@@ -317,18 +420,25 @@ static void launch_factor(const TriFactor& F, const cplx* b, cplx* x, hipStream_
         if (s.kind == 1) {
             hipLaunchKernelGGL(k_trsv_chain, dim3(1), dim3(1024), 0, st, s.l0, s.l1, F.grpptr.p, F.grpcnt.p, F.grpdense.p, F.dense.p,
                                F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
+        } else if (s.kind == 3) {
+            const TriFactor::Run& r = F.runs[(size_t)s.l0];
+            const cplx* D = F.rdense.p + r.dofs;
+            hipLaunchKernelGGL(k_run_ext, dim3((unsigned)r.R), dim3(256), 0, st, r.first, F.rowptr.p, F.col.p, F.val.p, F.rowid.p, b, x, F.racc.p);
+            for (int J = 0; J * RUN_BLOCK < r.R; ++J) {
+                hipLaunchKernelGGL(k_run_diag, dim3(1), dim3(64), 0, st, r.first, r.R, J, D, F.rowid.p, F.invd.p, F.racc.p, F.rx.p, x);
+                const int rem = r.R - (J + 1) * RUN_BLOCK;
+                if (rem > 0) hipLaunchKernelGGL(k_run_update, dim3((unsigned)((rem + 3) / 4)), dim3(256), 0, st, r.R, J, D, F.rx.p, F.racc.p);
+            }
         } else if (s.kind == 2) {
             const int first = F.h_grpptr[(size_t)s.l0], nrows = F.h_grpcnt[(size_t)s.l0], dofs = F.h_grpdense[(size_t)s.l0];
             hipLaunchKernelGGL(k_trsv_group_ext, dim3((unsigned)nrows), dim3(512), 0, st, first, F.rowptr.p, F.col.p, F.val.p, F.rowid.p, b, x, F.gacc.p);
             hipLaunchKernelGGL(k_trsv_group_dense, dim3(1), dim3(64), 0, st, first, nrows, dofs, F.dense.p, F.rowid.p, F.invd.p, F.gacc.p, x);
         } else {
             const int first = F.h_lvlptr[(size_t)s.l0], nrows = F.h_lvlptr[(size_t)s.l0 + 1] - first;
-            if (s.lpr == 64)
-                hipLaunchKernelGGL(k_trsv_level<64>, dim3((unsigned)(((int64_t)nrows * 64 + 255) / 256)), dim3(256), 0, st, first, nrows,
-                                   F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
-            else
-                hipLaunchKernelGGL(k_trsv_level<8>, dim3((unsigned)(((int64_t)nrows * 8 + 255) / 256)), dim3(256), 0, st, first, nrows,
-                                   F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x);
+#define LSFC_LEVEL(LPR) hipLaunchKernelGGL(k_trsv_level<LPR>, dim3((unsigned)(((int64_t)nrows * LPR + 255) / 256)), dim3(256), 0, st, first, nrows, \
+                                          F.rowptr.p, F.col.p, F.val.p, F.rowid.p, F.invd.p, b, x)
+            switch (s.lpr) { case 64: LSFC_LEVEL(64); break; case 32: LSFC_LEVEL(32); break; case 16: LSFC_LEVEL(16); break; default: LSFC_LEVEL(8); }
+#undef LSFC_LEVEL
         }
     }
 }
@@ -437,7 +547,10 @@ int lsfc_precond_create(lsfc_precond** out, int64_t N,
         build_factor(pc->U, N, U_rowptr, U_col, U_val, false);
         for (DevBuf<cplx>* b : { &pc->vin, &pc->y0, &pc->z, &pc->w, &pc->vout }) { b->alloc((size_t)N); LSFC_HIP(hipMemset(b->p, 0, b->bytes())); }
         pc->launches = 2;
-        for (const TriFactor* F : { &pc->L, &pc->U }) for (const auto& sg : F->segs) pc->launches += sg.kind == 2 ? 2 : 1;
+        for (const TriFactor* F : { &pc->L, &pc->U }) for (const auto& sg : F->segs) {
+            if (sg.kind == 3) { const int nb = (F->runs[(size_t)sg.l0].R + RUN_BLOCK - 1) / RUN_BLOCK; pc->launches += 2 * nb; }
+            else pc->launches += sg.kind == 2 ? 2 : 1;
+        }
         *out = pc.release();
     });
 }
