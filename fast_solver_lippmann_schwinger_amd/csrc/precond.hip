@@ -7,11 +7,17 @@
 // assembly of As / Msp, stay on the host and out of scope; what moves to the device is the part that runs once per
 // Arnoldi step, so the Krylov vector no longer crosses PCIe twice per step.
 //
-// Sparse triangular solves by level scheduling: rows are grouped by dependency depth; a wide level is one launch
-// over all its rows, a run of narrow levels (the long tail of an LU factor: the dense trailing separator block is
-// one row per level) is ONE single-workgroup launch that walks the levels with barriers.  The whole sequence
-// SpMV -> L solve -> U solve -> scatter is captured once in a hipGraph on fixed internal buffers and replayed per
-// apply: one graph launch instead of hundreds of kernel launches.
+// Sparse triangular solves by level scheduling: rows are grouped by dependency depth.  The factors of a 2D/3D stencil
+// matrix are deep and thin, so four kinds of steps are scheduled at set-up:
+//   * a wide or heavy level              one launch over all its rows, 8..64 lanes per row by row length
+//   * a run of light, narrow levels      ONE single-workgroup launch that walks them with barriers, 1024 / rows lanes
+//                                        per row; consecutive thin levels are fused into groups of <= 16 rows whose
+//                                        mutual coupling is a dense 16 x 16 block resolved by one wave in registers
+//   * a heavy group                      the same in two launches: one workgroup per row, then the dense block
+//   * a long sequence of thin levels     a dense run: coupling stored as a dense R x R block, blocked right-looking
+//                                        forward substitution (the trailing separator blocks of the factor)
+// The whole sequence SpMV -> L solve -> U solve -> scatter is captured once in a hipGraph on fixed internal buffers
+// and replayed per apply.
 #include "common.hpp"
 #include <algorithm>
 #include <complex>
