@@ -283,7 +283,12 @@ struct TriFactor {                 // one triangular factor, rows in level order
     int ngroups = 0;
 };
 
-static constexpr int NARROW = 128;        // levels with at most this many rows ...
+static int narrow_rows() {               // levels with at most this many rows (default 32: 42 -> 37 ms at N = 263 169 against
+                                         // 128; LSFC_PRECOND_NARROW, 8..128) ...
+    static const int v = [] { const char* e = getenv("LSFC_PRECOND_NARROW"); int n = e ? atoi(e) : 32; return n < 8 ? 8 : (n > 128 ? 128 : n); }();
+    return v;
+}
+#define NARROW narrow_rows()
 static constexpr int64_t CHAIN_NNZ = 8192; // ... and at most this many entries are walked inside a single workgroup
 static constexpr int RUN_THIN = 4;        // dense runs: consecutive levels of at most this many rows ...
 static constexpr int RUN_MIN = 96;        // ... totalling at least this many rows, cut into pieces of at most
