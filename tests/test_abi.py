@@ -28,6 +28,18 @@ def test_library_exports_every_declared_symbol():
     assert sorted(L.SIGNATURES) == names, "python binding and header disagree"
 
 
+def test_binding_argument_counts_match_the_header():
+    # every ctypes signature has exactly as many arguments as the C prototype it binds
+    import fast_solver_lippmann_schwinger_amd._lib as L
+    text = open(os.path.join(ROOT, "include", "lsfc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = dict(re.findall(r"\b(lsfc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+    for name, (_, args) in L.SIGNATURES.items():
+        params = protos[name].strip()
+        n = 0 if params in ("", "void") else len([a for a in params.split(",") if a.strip()])
+        assert n == len(args), f"{name}: header has {n} parameters, binding has {len(args)}"
+
+
 def test_padded_length_rule():
     # host arithmetic only: smallest of 2^k, 3*2^k, 5*2^k in [32, 2048] that is >= 2n
     import fast_solver_lippmann_schwinger_amd._lib as L
