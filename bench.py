@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark: fastconv applies/s on the 3D n=512^3 fp64 operator (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
 One "step" is one pass of the hot path, y = x + omega^2 * G * (nu .* x) (FastM3D `*`,
 src/FastConvolution3D.jl:31-37 of the reference), on a synthetic contrast with the vectors
 already resident in HBM.  N = 1: the whole 512^3 volume on one MI355X.  N > 1: the same volume
-slab-partitioned over N GPUs (strong scaling) with the RCCL all-to-all pencil transposes.
-Rank 0 prints ONE JSON line.  The CPU baseline (the numpy/scipy oracle, a port of the
-reference arithmetic -- the reference itself is Julia and cannot run here) is timed on rank 0
-at N = 1 only, on a bounded sample, and is never the thing measured as `value`.
+slab-partitioned over N GPUs (strong scaling) with the RCCL all-to-all pencil transposes, one
+process per GPU.  Started under torch.distributed.run the process is one rank of the job; started
+directly with --gpus N > 1 it launches the N ranks itself (torch.distributed.run as a child process,
+before anything in this process touches the GPU) and relays rank 0's line.  `--single-process` runs
+the N-GPU job from ONE host process instead (lsfc_plan_create_gv3d_multi: the form a single Julia
+host uses).  Rank 0 prints ONE JSON line.
+
+Before any throughput is reported the same build is checked against the CPU oracle on the bench's own
+(nu, omega) recipe at n = 64 and n = 128 (n = 64 only when N > 1): relative l2 > 1e-10 aborts the run.
+The CPU baseline (the numpy/scipy oracle, a port of the reference arithmetic -- the reference itself
+is Julia and cannot run here) is timed on rank 0 at N = 1 only, on a bounded sample, and is never
+the thing measured as `value`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_POINT = 568.0         # 35 complex + 1 real per grid point per apply
+PARITY_TOL = 1e-10              # BASELINE.json north_star
 
 
 def synthetic_nu(n, lo, hi):
@@ -44,31 +55,62 @@ def synthetic_nu(n, lo, hi):
     return out.reshape(-1)
 
 
-def _cpu_apply_seconds(n, reps, budget_s):
-    """best-of-`reps` wall time of one oracle apply (reduced-2n variant) at grid size n; (None, 0) if it cannot run"""
-    from oracle import lsfc_oracle as o
-    try:
-        # timing does not depend on the symbol's values: a cheap deterministic symbol of the right shape
-        a = np.linspace(0.1, 1.0, 2 * n)
-        G2 = (a[:, None, None] + 1j * a[None, :, None]) * a[None, None, :]
-        rng = np.random.default_rng(3)
-        nu = rng.uniform(-0.3, 0.3, n ** 3)
-        b = rng.standard_normal(n ** 3) + 1j * rng.standard_normal(n ** 3)
-        best, done, t_all = float("inf"), 0, time.time()
-        while done < reps and (done == 0 or time.time() - t_all < budget_s):
-            t0 = time.time()
-            o.apply_reduced(G2, nu, float(n), b, (n, n, n))
-            best = min(best, time.time() - t0)
-            done += 1
-        return best, done
-    except MemoryError:
-        return None, 0
+def bench_vector(n, lo, hi):
+    """x = g1 + i g2, planes [lo, hi); the same on every rank layout"""
+    rng = np.random.default_rng(20250224)
+    v = rng.standard_normal(2 * n ** 3).view(np.complex128) if n <= 128 else None
+    if v is not None:
+        return v[lo * n * n:hi * n * n].copy()
+    rng = np.random.default_rng(20250224 + lo)
+    return rng.standard_normal(2 * (hi - lo) * n * n).view(np.complex128)
 
 
-def cpu_baseline(n_target):
+# --------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with N > 1 and no torchrun environment
+# --------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(argv, n):
+    """the child command that runs this script as n ranks on one node (no GPU is touched by the parent)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, n):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    proc = subprocess.run(launcher_command(argv, n), env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"[bench] the {n}-rank job failed (exit code {proc.returncode})", file=sys.stderr, flush=True)
+        raise SystemExit(proc.returncode or 1)
+    print(line, flush=True)
+    raise SystemExit(0)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# CPU baseline and parity gate (the only users of oracle/ in this file)
+# --------------------------------------------------------------------------------------------------------------
+def cpu_baseline(n_target, nu, xvec):
     """Oracle (port of the reference arithmetic, reduced-2n variant -- the literal (4n)^3 arrays are 137 GB each at
-    n=512) timed on this box's host cores on a bounded sample: ONE apply at the real size when the host can hold it
-    (~70 GB of work arrays at n=512, ~15-25 s), else n=256 measured and scaled by N log N."""
+    n=512) timed on this box's host cores on a bounded sample of the SAME workload: the bench's contrast and vector at
+    the real size when the host can hold it (~70 GB of work arrays at n=512), else n=256 measured and scaled by
+    N log N.  The symbol handed to the timed apply is a cheap deterministic array of the right shape (evaluating the
+    true 1024^3 symbol on the host takes minutes and its values do not change the FFT time); results are NOT compared
+    here -- parity of this build is established by the gate above and by tests/."""
+    from oracle import lsfc_oracle as o
     cores = os.cpu_count() or 1
     avail_gb = 0.0
     try:
@@ -76,24 +118,68 @@ def cpu_baseline(n_target):
         avail_gb = psutil.virtual_memory().available / 1e9
     except Exception:
         pass
+
+    def timed(n, nu_n, x_n, max_reps, budget_s):
+        a = np.linspace(0.1, 1.0, 2 * n)
+        G2 = (a[:, None, None] + 1j * a[None, :, None]) * a[None, None, :]
+        times, t_all = [], time.time()
+        while len(times) < max_reps and (not times or time.time() - t_all + times[-1] < budget_s):
+            t0 = time.time()
+            o.apply_reduced(G2, nu_n, float(n), x_n, (n, n, n))
+            times.append(time.time() - t0)
+        return times
+
     need_gb = 5.5 * 16 * (2 * n_target) ** 3 / 1e9
-    if cores >= 32 and avail_gb > need_gb:
-        best, done = _cpu_apply_seconds(n_target, 1, 0)
-        if best is not None:
-            return {"value": 1.0 / best, "unit": "applies/s", "cores": cores, "kind": "port",
-                    "sample": f"oracle reduced-2n apply (scipy.fft, workers={cores}), 3D n={n_target}, one apply at the full size, no warm-up",
-                    "measured_s_per_apply_sample": best, "sample_n": n_target}
-    n = 256 if n_target >= 256 else n_target
-    _cpu_apply_seconds(n, 1, 0)                                  # warm-up
-    best, done = _cpu_apply_seconds(n, 3, 40)
-    scale = 1.0
-    note = f"oracle reduced-2n apply (scipy.fft, workers={cores}), 3D n={n}, best of {done}"
+    n, scale = n_target, 1.0
+    if not (cores >= 32 and avail_gb > need_gb) and n_target > 256:
+        n = 256
     if n != n_target:
+        nu, xvec = synthetic_nu(n, 0, n), bench_vector(n, 0, n)
         Nt, Ns = (2 * n_target) ** 3, (2 * n) ** 3
         scale = (Nt * np.log2(Nt)) / (Ns * np.log2(Ns))
-        note += f"; extrapolated to n={n_target} by N log N (x{scale:.2f}): the host cannot hold or finish an n={n_target} apply within the sample budget"
+    try:
+        times = timed(n, nu, xvec, 3, 45.0)
+    except MemoryError:
+        return None
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    note = (f"oracle reduced-2n apply (scipy.fft, workers={cores}), 3D n={n}, bench contrast and vector, "
+            + (f"1 warm-up + {len(times) - 1} timed, best-of" if len(times) > 1 else "one apply, no warm-up (a second apply did not fit the 45-s sample budget)"))
+    if n != n_target:
+        note += f"; extrapolated to n={n_target} by N log N (x{scale:.2f}): the host cannot hold an n={n_target} apply"
     return {"value": 1.0 / (best * scale), "unit": "applies/s", "cores": cores, "kind": "port", "sample": note,
-            "measured_s_per_apply_sample": best, "sample_n": n}
+            "measured_s_per_apply_sample": best, "all_sample_s": times, "sample_n": n}
+
+
+def parity_gate(lsfc, sizes, rank, world, local_rank, dist):
+    """the bench's (nu, omega = 1/h) recipe at small n on THIS build and device(s) vs the CPU oracle"""
+    from oracle import lsfc_oracle as o
+    worst = {}
+    for n in sizes:
+        h = 1.0 / n
+        omega = 1.0 / h
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        b = bench_vector(n, 0, n)
+        nu = synthetic_nu(n, 0, n)
+        if world == 1:
+            xg = -0.5 + h * np.arange(n)
+            M = lsfc.buildFastConvolution3D(xg, xg, xg, None, None, None, h, omega, nu, device=local_rank)
+        else:
+            from fast_solver_lippmann_schwinger_amd.distributed import build_distributed_3d
+            M = build_distributed_3d(n, h, omega, nu[lo * n * n:hi * n * n], rank, world, local_rank)
+        y = M * b[lo * n * n:hi * n * n]
+        M.close()
+        G2 = o.reduced_symbol_gv3d(n, n, n, n * h, omega, patch_singular=False)
+        ref = o.apply_reduced(G2, nu, omega, b, (n, n, n))[lo * n * n:hi * n * n]
+        err = float(np.linalg.norm(y - ref) / np.linalg.norm(ref))
+        if dist is not None:
+            import torch
+            t = torch.tensor([err], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            err = float(t.item())
+        worst[f"n{n}"] = err
+        if not err <= PARITY_TOL:
+            raise SystemExit(f"[bench] PARITY GATE FAILED at n={n}: relative l2 {err:.3e} > {PARITY_TOL:g} vs the CPU oracle; no throughput reported")
+    return worst
 
 
 def main():
@@ -103,18 +189,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=int(os.environ.get("LSFC_BENCH_N", 512)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true", help="skip the oracle check (profiling runs only; the line then says so)")
     ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (rehearsal of the multi-GPU path)")
+    ap.add_argument("--single-process", action="store_true", help="drive all --gpus devices from this one process (multi-device plan)")
     args = ap.parse_args()
-
-    import torch
-    import fast_solver_lippmann_schwinger_amd as lsfc
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and "RANK" not in os.environ and not args.single_process:
+        self_launch(sys.argv[1:], args.gpus)             # never returns; nothing above has touched the GPU
+    if "RANK" in os.environ and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+
+    import torch
+    import fast_solver_lippmann_schwinger_amd as lsfc
+
     n = args.n
     N = n ** 3
     h = 1.0 / n
@@ -127,88 +217,129 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    if world == 1 and not args.force_dist:
-        nu = synthetic_nu(n, 0, n)
+    parity = None
+    if not args.no_parity_gate and not args.single_process:
+        parity = parity_gate(lsfc, [64, 128] if world == 1 else [64], rank, world, local_rank, dist if world > 1 else None)
+
+    nu_host = None
+    multi = None
+    if args.single_process and args.gpus > 1:
+        from fast_solver_lippmann_schwinger_amd.distributed import MultiDeviceFastM3D
+        nu_host = synthetic_nu(n, 0, n)
+        multi = MultiDeviceFastM3D(n, h, omega, nu_host, devices=list(range(args.gpus)))
+        world_eff = args.gpus
+    elif world == 1 and not args.force_dist:
+        nu_host = synthetic_nu(n, 0, n)
         x = -0.5 + h * np.arange(n)
-        M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, omega, nu, device=local_rank)
+        M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, omega, nu_host, device=local_rank)
         nloc = N
+        world_eff = 1
     else:
         from fast_solver_lippmann_schwinger_amd.distributed import build_distributed_3d
         lo, hi = rank * n // world, (rank + 1) * n // world
         M = build_distributed_3d(n, h, omega, synthetic_nu(n, lo, hi), rank, world, local_rank)
         nloc = (hi - lo) * n * n
+        world_eff = world
 
-    g = torch.Generator(device=dev); g.manual_seed(20250224 + rank)
-    xb = torch.randn(nloc, dtype=torch.complex128, device=dev, generator=g)
-    yb = torch.empty_like(xb)
+    if multi is not None:
+        out = multi.bench(args.steps, args.warmup)
+        elapsed, stages = out["elapsed_s"], out["stages"]
+        pipeline, padded = "pruned-hip", list(multi.padded_dims)
+        nloc = N // args.gpus
+    else:
+        lo = rank * n // world_eff
+        xb = torch.from_numpy(bench_vector(n, lo, lo + nloc // (n * n))).to(dev)
+        yb = torch.empty_like(xb)
 
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        def sync():
             torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        M.mul_(yb, xb)
-    M.synchronize()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        M.mul_(yb, xb)
-    M.synchronize()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        for _ in range(args.warmup):
+            M.mul_(yb, xb)
+        M.synchronize()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            M.mul_(yb, xb)
+        M.synchronize()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        # per-kernel roofline: HIP events on the plan's stream around every stage of one apply.  With more than one
+        # rank the stages contain collectives, so a failure must take the whole job down (no per-rank try/except:
+        # a rank that skipped them would leave the others blocked in ncclRecv).
+        if world_eff > 1:
+            stages = lsfc.profile_apply(M, xb, yb, reps=5)
+        else:
+            try:
+                stages = lsfc.profile_apply(M, xb, yb, reps=5)
+            except Exception as e:                   # never lose the headline line to the optional per-stage profile
+                print(f"[bench] per-stage profile unavailable: {e}", file=sys.stderr, flush=True)
+                stages = [("apply (whole; per-stage profile unavailable)", elapsed / args.steps * 1e3, BYTES_PER_POINT * nloc)]
+        pipeline, padded = M.pipeline, list(M.padded_dims)
 
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps / elapsed
 
-    # per-kernel roofline: HIP events on the plan's stream around every stage of one apply
-    try:
-        stages = lsfc.profile_apply(M, xb, yb, reps=5)
-    except Exception as e:                   # never lose the headline line to the optional per-stage profile
-        print(f"[bench] per-stage profile unavailable: {e}", file=sys.stderr, flush=True)
-        stages = [("apply (whole; per-stage profile unavailable)", ms_per_step, BYTES_PER_POINT * nloc)]
     # dominant COMPUTE kernel (the un-overlapped all-to-all stages of the multi-GPU profile are listed, not ranked:
     # they are bounded by the xGMI links, not by HBM)
     dom = max((s for s in stages if not s[0].startswith("alltoall")), key=lambda s: s[1])
-    traffic = None
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and world == 1:
+    if os.path.exists(tpath) and world_eff == 1 and n == 512:
         try:
             traffic = json.load(open(tpath)).get(dom[0])
+            traffic_src = ("profiles/traffic_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/one_apply.py 512 on this "
+                           "build (per launch; NOT collected in this run -- counters need the profiler)")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom[0], "achieved": dom[2] / (dom[1] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": dom[2] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": dom[2] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_over_algorithmic": (traffic / dom[2]) if traffic else None,
                 "algorithmic_bytes_per_launch": dom[2], "avg_launch_ms": dom[1],
                 "stages": [{"kernel": s[0], "ms": s[1], "GBps": s[2] / (s[1] * 1e-3) / 1e9} for s in stages]}
     whole = BYTES_PER_POINT * N / (ms_per_step * 1e-3) / 1e9
 
     out = {"metric": "fastconv applies/sec, 3D n=512^3 fp64 (FastM3D apply)" if n == 512 else f"fastconv applies/sec, 3D n={n}^3 fp64",
-           "value": value, "unit": "applies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "value": value, "unit": "applies/s", "n_gpus": world_eff, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"3D n={n}^3 complex fp64 operator apply y = x + w^2 G*(nu.*x), Greengard-Vico truncated-kernel symbol, "
                                   f"omega=1/h={omega:g}, sum-of-8-Gaussians contrast, vectors resident in HBM",
-                      "n": n, "omega": omega, "pipeline": M.pipeline, "padded_grid": list(M.padded_dims),
-                      "parallelism": "single GPU" if world == 1 else f"z-slabs over {world} GPUs, 2 RCCL all-to-all per apply"},
-           "achieved_algorithmic_GBps_per_gpu": whole / world, "hbm_roofline_frac_whole_apply": whole / world / HBM_PEAK_GBPS,
+                      "n": n, "omega": omega, "pipeline": pipeline, "padded_grid": padded,
+                      "parallelism": "single GPU" if world_eff == 1 else
+                                     (f"z-slabs over {world_eff} GPUs, 2 all-to-all slab transposes per apply, "
+                                      + ("ONE host process driving all devices" if multi is not None else "one process per GPU, RCCL send/recv"))},
+           "achieved_algorithmic_GBps_per_gpu": whole / world_eff, "hbm_roofline_frac_whole_apply": whole / world_eff / HBM_PEAK_GBPS,
+           "parity_rel_l2": parity if parity is not None else "gate skipped (--no-parity-gate / --single-process)",
+           "parity_tol": PARITY_TOL,
            "roofline": roofline}
-    if world > 1:
+    if world_eff > 1:
         # the two slab transposes of an apply move 2 * 2N complex in total; rank p sends 2N*16 B*(P-1)/P^2 per transpose
         # over its P-1 direct xGMI links (one link per GPU pair).  A model, not a measurement: see DESIGN.md section 5.
-        per_link = 2 * (2.0 * N * 16.0) / world ** 2
+        per_link = 2 * (2.0 * N * 16.0) / world_eff ** 2
         out["link_model"] = {"bytes_per_link_per_direction_per_apply": per_link,
                              "ms_at_76.8_GBps_per_direction": per_link / 76.8e9 * 1e3,
                              "note": "xGMI time floor of the two all-to-all transposes at the nominal per-direction link rate; "
                                      "the apply cannot be faster than this however well it overlaps"}
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n)
-        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        # what the transport saw: the un-overlapped exchange stages of the per-stage profile
+        ex = {s[0]: s[1] for s in stages if s[0].startswith("alltoall")}
+        out["exchange"] = {"nranks": world_eff, "transport": (multi.transport if multi is not None else "rccl send/recv, pairwise schedule"),
+                           "unoverlapped_ms": ex,
+                           "achieved_GBps_per_link_per_direction": {k: (per_link / 2) / (v * 1e-3) / 1e9 for k, v in ex.items() if v > 0},
+                           "note": "each exchange ships bytes_per_link_per_direction_per_apply / 2 over every one of the P-1 links of a GPU; "
+                                   "production applies overlap the exchanges with the y/z passes (K pipeline chunks)"}
+    if world_eff == 1 and rank == 0 and not args.no_cpu_baseline:
+        cb = cpu_baseline(n, nu_host, xb.cpu().numpy())
+        if cb is not None:
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = value / cb["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

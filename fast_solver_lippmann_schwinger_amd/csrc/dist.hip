@@ -191,7 +191,7 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     LSFC_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
     LSFC_REQUIRE(n % 2 == 0 && m % 2 == 0 && l % 2 == 0, "even grid sizes only");
     LSFC_REQUIRE(l % nranks == 0, "l = %lld is not divisible by the number of ranks %d", (long long)l, nranks);
-    for (int64_t v : { n, m, l }) LSFC_REQUIRE(pruned_best_length(v) != 0, "distributed plan: grid sizes up to 1024 per axis");
+    for (int64_t v : { n, m, l }) LSFC_REQUIRE(pruned_best_length(v) != 0 && pruned_best_length(v) <= 4 * v, "distributed plan: grid sizes from 8 to 1024 per axis");
     LSFC_REQUIRE((pruned_best_length(n) / 8) % nranks == 0 && is_pow2(nranks),
                  "number of ranks must be a power of two dividing Lx/8 (Lx = %d is the padded line length for n = %lld)", pruned_best_length(n), (long long)n);
     std::unique_ptr<lsfc_plan> p(new lsfc_plan());
@@ -220,6 +220,11 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     d->force_comm = !sim && getenv("LSFC_DIST_FORCE_COMM") && getenv("LSFC_DIST_FORCE_COMM")[0] == '1';
     if (!sim && (nranks > 1 || d->force_comm)) {
         LSFC_REQUIRE(id, "NULL unique id");
+        // an all-zero id means the caller never received rank 0's id (no broadcast happened): ncclCommInitRank would
+        // block forever on every rank instead of failing
+        bool nonzero = false;
+        for (int i = 0; i < LSFC_UNIQUE_ID_BYTES; ++i) nonzero = nonzero || id[i] != 0;
+        LSFC_REQUIRE(nonzero, "the RCCL unique id is all zeros: ship the bytes of lsfc_dist_unique_id() from rank 0 to every rank first");
         ncclUniqueId uid; static_assert(sizeof(uid) == LSFC_UNIQUE_ID_BYTES, "unique id size");
         memcpy(&uid, id, sizeof uid);
         ncclComm_t comm, comm2;

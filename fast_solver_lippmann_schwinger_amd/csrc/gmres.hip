@@ -164,10 +164,15 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
             fetch_h(k + 1);
             nrm = w->hpin[k].x;
             if (o.orth == LSFC_ORTH_DGKS) {
+                // IterativeSolvers orthogonalize.jl: `while nrm < projection_size / sqrt(2)`, projection_size being
+                // the norm of the latest correction; the corrections accumulate into the Hessenberg column
                 double proj = 0.0;
                 for (int i = 0; i < k; ++i) proj += w->hpin[i].x * w->hpin[i].x + w->hpin[i].y * w->hpin[i].y;
-                if (nrm < std::sqrt(proj) / std::sqrt(2.0)) {
-                    std::vector<cplx> h1(w->hpin, w->hpin + k);
+                proj = std::sqrt(proj);
+                std::vector<cplx> hsum(w->hpin, w->hpin + k);
+                bool again = false;
+                for (int pass = 0; nrm < proj / std::sqrt(2.0) && pass < 8; ++pass) {     // (8: guard against a NaN-free but stagnating loop)
+                    again = true;
                     for (int j0 = 0; j0 < k; j0 += 64) {
                         const int kc = std::min(64, k - j0);
                         blas_multidot(Vcol(j0), N, kc, wv, w->partial.p, w->hdev.p + j0, N, st);
@@ -180,9 +185,15 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
                     blas_nrm2(wv, w->partial.p, w->hdev.p + k, N, st, multi);
                     finish_nrm(w->hdev.p + k);
                     fetch_h(k + 1);
-                    for (int i = 0; i < k; ++i) { w->hpin[i].x += h1[i].x; w->hpin[i].y += h1[i].y; }
+                    proj = 0.0;
+                    for (int i = 0; i < k; ++i) {
+                        proj += w->hpin[i].x * w->hpin[i].x + w->hpin[i].y * w->hpin[i].y;
+                        hsum[i].x += w->hpin[i].x; hsum[i].y += w->hpin[i].y;
+                    }
+                    proj = std::sqrt(proj);
                     nrm = w->hpin[k].x;
                 }
+                if (again) for (int i = 0; i < k; ++i) w->hpin[i] = hsum[i];
             }
             blas_scale_inv_dev(wv, w->hdev.p + k, N, st);
         }

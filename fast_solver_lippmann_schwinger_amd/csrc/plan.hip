@@ -123,6 +123,9 @@ static bool pruned_eligible(const lsfc_plan* p) {
     for (int d = 0; d < p->ndim; ++d) {
         const int L = pruned_best_length(p->dims[d]);
         if (L == 0) return false;
+        // the slab-wise Greengard-Vico generator samples the literal 4n lattice: a working line longer than 4n (an axis of
+        // fewer than 8 points next to long ones) has no such samples -> exact 2n grid through rocFFT
+        if (p->ndim == 3 && L > 4 * p->dims[d]) return false;
         ratio *= (double)L / (2.0 * (double)p->dims[d]);
     }
     return ratio <= 4.0;

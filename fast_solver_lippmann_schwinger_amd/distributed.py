@@ -23,9 +23,14 @@ def slab_range(l, rank, nranks):
 
 
 def exchange_unique_id(rank, nranks, group=None):
-    """Rank 0 creates the RCCL unique id; everyone receives it through torch.distributed."""
+    """Rank 0 creates the RCCL unique id; everyone receives it through torch.distributed.  With more than one rank an
+    initialised process group is mandatory: without the broadcast the other ranks would hand ncclCommInitRank an id
+    nobody else has and block forever (pass ``uid=`` to build_distributed_3d to ship the id some other way)."""
     import torch
     import torch.distributed as dist
+    if nranks > 1 and not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError(f"exchange_unique_id: {nranks} ranks but torch.distributed is not initialised; call "
+                           "dist.init_process_group first or pass the 128-byte id of lsfc_dist_unique_id() as uid=")
     buf = (C.c_ubyte * L.LSFC_UNIQUE_ID_BYTES)()
     if rank == 0:
         L.check(L.load().lsfc_dist_unique_id(buf))
@@ -38,7 +43,7 @@ def exchange_unique_id(rank, nranks, group=None):
     return buf
 
 
-def build_distributed_3d(n, h, k, nu_local, rank, nranks, device, m=None, l=None, flags=0, group=None):
+def build_distributed_3d(n, h, k, nu_local, rank, nranks, device, m=None, l=None, flags=0, group=None, uid=None):
     """Distributed `buildFastConvolution3D` on the half-open grid x = x0 + h*(0..n-1): this rank passes the contrast
     on its own z planes (flat, x fastest).  Returns a FastM3D whose vectors are the local slabs."""
     m = n if m is None else m
@@ -48,7 +53,10 @@ def build_distributed_3d(n, h, k, nu_local, rank, nranks, device, m=None, l=None
     if nuv.size != n * m * (hi - lo):
         raise ValueError("DimensionMismatch: nu_local")
     box = n * h                                   # |x[end] - x[1]| + h
-    uid = exchange_unique_id(rank, nranks, group)
+    if uid is None:
+        uid = exchange_unique_id(rank, nranks, group)
+    else:
+        uid = (C.c_ubyte * L.LSFC_UNIQUE_ID_BYTES)(*bytes(uid))
     plan = C.c_void_p()
     L.check(L.load().lsfc_dist_plan_create_gv3d(C.byref(plan), n, m, l, float(box), float(k), nuv.ctypes.data_as(C.c_void_p),
                                                 flags, device, rank, nranks, uid))

@@ -262,7 +262,11 @@ def buildFastConvolution(x, y, h, k, nu, quadRule="trapezoidal", flags=0, device
     plan = C.c_void_p()
     if quadRule == "trapezoidal":
         _, D = referenceValsTrapRule()
-        D0 = D[int(round(k * h)) - 1]                       # D[round(Int, k*h)]
+        idx = int(round(k * h))                             # D[round(Int, k*h)], 1-based (src/FastConvolution.jl:175-176)
+        if not 1 <= idx <= len(D):
+            raise IndexError(f"BoundsError: attempt to access {len(D)}-element Vector at index [{idx}] "
+                             "(D[round(Int, k*h)], src/FastConvolution.jl:176)")
+        D0 = D[idx - 1]
         L.check(L.load().lsfc_plan_create_trap2d(C.byref(plan), n, m, float(x[0]), float(y[0]), float(h), float(k),
                                                  float(D0.real), float(D0.imag), nuv.ctypes.data_as(C.c_void_p), flags, device))
         return FastM(None, nuv, 2 * n - 1, 2 * m - 1, n, m, k, quadRule="trapezoidal", _plan=plan)

@@ -225,8 +225,11 @@ int lsfc_time_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int rep
 int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int reps,
                        int max_stages, const char** names, double* ms, double* bytes, int* nstages);
 
-/* Tuning knobs of the pruned pipeline (benchmarks / autotuning): "split_x", "split_s", "sym_prefetch",
- * "ytile_g", "ytile_z".  Results never depend on them. */
+/* Tuning knobs of the pruned pipeline (benchmarks / autotuning), the run-time form of the LSFC_* environment
+ * switches of DESIGN.md section 3: "split_x", "split_s" (re/im-split LDS exchanges of the x / y passes), "split_z",
+ * "sym_prefetch", "tw_lds", "z_half" (fused pass: split exchanges, symbol prefetch, LDS-resident stage twiddles,
+ * half-tile form), "ytile_g", "ytile_z" (block-order tile of the y passes).  Any other key is LSFC_EINVAL.
+ * Results never depend on them. */
 int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value);
 
 /* ---- device memory helpers for hosts without a HIP binding ---------------- */

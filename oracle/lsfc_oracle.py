@@ -172,7 +172,10 @@ def build_fast_convolution(x, y, h, k, nu, quadRule="trapezoidal", patch_singula
     X, Y = grid2d(x, y)
     if quadRule == "trapezoidal":
         _, D = reference_vals_trap_rule()
-        D0 = D[int(round(k * h)) - 1]                    # :176 (1-based D[round(Int,k*h)])
+        idx = int(round(k * h))                          # :176 (1-based D[round(Int,k*h)]; Julia throws BoundsError outside 1..6)
+        if not 1 <= idx <= len(D):
+            raise IndexError(f"BoundsError: attempt to access {len(D)}-element Vector at index [{idx}]")
+        D0 = D[idx - 1]
         Ge = build_gconv(x, y, h, n, m, D0, k)
         GFFT = _fftn(Ge)
         return FastM(GFFT, np.asarray(nu(X, Y), dtype=np.float64), 2 * n - 1, 2 * m - 1, n, m, float(k))
@@ -313,11 +316,16 @@ def apply_reduced(G2, nu, omega, b, dims):
     return b + omega**2 * convolve_reduced(G2, nu * b, dims)
 
 
-def reduced_symbol_gv3d(n, m, l, box, k, patch_singular=True, chunk=8):
+def reduced_symbol_gv3d(n, m, l, box, k, patch_singular=True, chunk=8, threads=None):
     """Reduced (2n,2m,2l) FFT-order symbol of buildFastConvolution3D WITHOUT
     materialising the (4n)^3 cube: the inverse transform of the centred literal
     symbol is done plane-chunk by plane-chunk along x with pruned outputs.
-    ``box`` = |x_end - x_1| + h.  Mirrors what the HIP symbol generator does."""
+    ``box`` = |x_end - x_1| + h.  Mirrors what the HIP symbol generator does.
+
+    Two exact shortcuts keep the full-size cases (n = 256, 512) affordable on the host: the literal symbol depends on
+    k only through kx^2 + ky^2 + kz^2, so the samples at +j along an axis are bit-identical copies of those at -j and
+    are copied, not re-evaluated (one octant of closed-form evaluations instead of the cube); and independent plane chunks are evaluated on a thread pool (numpy and scipy.fft release the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
     Lp, L = 4 * box, 1.8 * box
     kx = (2 * np.pi / Lp) * np.arange(-2 * n, 2 * n, dtype=np.float64)
     ky = (2 * np.pi / Lp) * np.arange(-2 * m, 2 * m, dtype=np.float64)
@@ -326,15 +334,28 @@ def reduced_symbol_gv3d(n, m, l, box, k, patch_singular=True, chunk=8):
     iz = np.concatenate([np.arange(0, l), np.arange(3 * l, 4 * l)])
     ix = np.concatenate([np.arange(0, n), np.arange(3 * n, 4 * n)])
     t2 = np.empty((4 * n, 2 * m, 2 * l), dtype=np.complex128)
-    for x0 in range(0, 4 * n, chunk):
-        xs = slice(x0, min(4 * n, x0 + chunk))
-        S = np.sqrt(kx[xs, None, None]**2 + ky[None, :, None]**2 + kz[None, None, :]**2)
-        g = gtruncated3d(L, float(k), S, patch_singular)
+    threads = threads or max(1, min(_WORKERS, 32))
+    inner = max(1, _WORKERS // threads)
+    ky2, kz2 = ky[None, :, None]**2, kz[None, None, :]**2
+
+    def planes(x0):
+        xs = slice(x0, min(2 * n + 1, x0 + chunk))                 # kx = -2n .. 0 only
+        # the same holds along y and z: evaluate the quadrant ky <= 0, kz <= 0 and fill the rest with bit-identical copies
+        S = np.sqrt(kx[xs, None, None]**2 + ky2[:, :2 * m + 1] + kz2[:, :, :2 * l + 1])     # src/FastConvolution3D.jl:98
+        gq = gtruncated3d(L, float(k), S, patch_singular)
+        g = np.empty((gq.shape[0], 4 * m, 4 * l), dtype=np.complex128)
+        g[:, :2 * m + 1, :2 * l + 1] = gq
+        g[:, 2 * m + 1:, :2 * l + 1] = gq[:, 2 * m - 1:0:-1, :]
+        g[:, :, 2 * l + 1:] = g[:, :, 2 * l - 1:0:-1]
         g = sfft.ifftshift(g, axes=(1, 2))
-        g = sfft.ifftn(g, axes=(1, 2), workers=_WORKERS)
-        t2[xs] = g[:, iy][:, :, iz]
-    t2 = sfft.ifft(sfft.ifftshift(t2, axes=0), axis=0, workers=_WORKERS)[ix]
-    return _fftn(t2)
+        g = sfft.ifft(g, axis=2, workers=inner, overwrite_x=True)[:, :, iz]       # pruned outputs: z first, then y on half the data
+        t2[xs] = sfft.ifft(g, axis=1, workers=inner, overwrite_x=True)[:, iy]
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(planes, range(0, 2 * n + 1, chunk)))
+    t2[2 * n + 1:] = t2[2 * n - 1:0:-1]                            # kx = +j  <-  kx = -j, j = 1 .. 2n-1
+    t2 = sfft.ifft(sfft.ifftshift(t2, axes=0), axis=0, workers=_WORKERS, overwrite_x=True)[ix]
+    return sfft.fftn(t2, workers=_WORKERS, overwrite_x=True)
 
 
 # ----------------------------------------------------------------------------
@@ -447,11 +468,16 @@ def gmres(x, A, b, Pl=None, abstol=0.0, reltol=None, restart=None, maxiter=None,
             h[:] = V[:, :k].conj().T @ w
             w = w - V[:, :k] @ h
             nrm = np.linalg.norm(w)
-            if orth_meth == "DGKS" and nrm < np.linalg.norm(h) / np.sqrt(2.0):
-                corr = V[:, :k].conj().T @ w
-                w = w - V[:, :k] @ corr
-                h += corr
-                nrm = np.linalg.norm(w)
+            if orth_meth == "DGKS":
+                # orthogonalize.jl: repeat `while nrm < projection_size / sqrt(2)`, projection_size being the norm of
+                # the latest correction
+                proj = np.linalg.norm(h)
+                while nrm < proj / np.sqrt(2.0):
+                    corr = V[:, :k].conj().T @ w
+                    proj = np.linalg.norm(corr)
+                    w = w - V[:, :k] @ corr
+                    h += corr
+                    nrm = np.linalg.norm(w)
         V[:, k] = w * (1.0 / nrm)
         H[k, k - 1] = nrm
         nullvec[k] = -np.conj(np.vdot(nullvec[:k], H[:k, k - 1]) / H[k, k - 1])   # update_residual!

@@ -115,6 +115,26 @@ def test_sizes_that_are_not_powers_of_two_3d(lsfc, dims):
     assert Mr.pipeline == "rocfft-reduced" and rel_err(Mr * b, ref) < TOL
 
 
+@pytest.mark.parametrize("dims", [(6, 16, 16), (4, 32, 32), (16, 6, 32)])
+def test_builder_3d_tiny_axis_next_to_long_ones(lsfc, dims):
+    # an axis of fewer than 8 points would need a working line (32) longer than the literal 4n lattice the slab-wise
+    # Greengard-Vico generator samples: such plans fall back to rocFFT on the exact 2n grid instead of failing
+    n, m, l = dims
+    h = 1.0 / 16
+    x, y, z = (-0.5 + h * np.arange(v) for v in dims)
+    X, Y, Z = o.grid3d(x, y, z)
+    k = 9.0
+    M = lsfc.buildFastConvolution3D(x, y, z, X, Y, Z, h, k, o.gaussian_bump)
+    assert M.pipeline == "rocfft-reduced" and M.padded_dims == (2 * n, 2 * m, 2 * l)
+    Mo = o.build_fast_convolution3d(x, y, z, X, Y, Z, h, k, o.gaussian_bump)
+    b = o.random_vector(n * m * l)
+    # (the reference's FFTconvolution allocates (ne, ne, le), src/FastConvolution3D.jl:48, and cannot run a non-cubic
+    # grid itself; its arithmetic on the reduced grid is the comparator)
+    G2 = o.reduce_symbol(Mo.GFFT, dims)
+    assert rel_err(M * b, o.apply_reduced(G2, Mo.nu, k, b, dims)) < TOL
+    assert rel_err(lsfc.FFTconvolution(M, b), o.convolve_reduced(G2, b, dims)) < TOL
+
+
 def test_reference_example_size_n48_builder(lsfc):
     # examples/example3D.jl uses n = 48 (h = 1/48, k = 48): builder on the device vs the oracle's literal builder
     n = 48
