@@ -75,6 +75,9 @@ SIGNATURES = {
     "lsfc_dist_plan_create_gv3d": (_I, [_PP, _L, _L, _L, _D, _D, _P, _U, _I, _I, _I, _P]),
     "lsfc_dist_sim_plan_create_gv3d": (_I, [_PP, _L, _L, _L, _D, _D, _P, _U, _I, _I, _I]),
     "lsfc_dist_sim_apply": (_I, [_PP, _I, _PP, _PP, _I]),
+    "lsfc_plan_create_gv3d_multi": (_I, [_PP, _L, _L, _L, _D, _D, _P, _U, C.POINTER(_I), _I]),
+    "lsfc_multi_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_L), C.POINTER(C.c_char_p)]),
+    "lsfc_multi_apply_dev": (_I, [_P, _PP, _PP, _I]),
     "lsfc_last_error": (C.c_char_p, []),
     "lsfc_padded_length": (_I, [C.c_int64]),
     "lsfc_version": (C.c_char_p, []),

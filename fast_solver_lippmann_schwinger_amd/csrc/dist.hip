@@ -14,6 +14,8 @@
 #include "pointwise.hpp"
 #include <rccl/rccl.h>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace lsfc {
@@ -103,6 +105,7 @@ static void exchange(lsfc_plan* p, int c, bool back, hipStream_t st, int part = 
 void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta) {
     DistState* d = p->dist.get();
     LSFC_REQUIRE(!d->sim, "simulated ranks are driven through lsfc_dist_sim_apply");
+    LSFC_REQUIRE(!d->member, "the ranks of a multi-device plan are driven through their parent plan");
     hipStream_t st = p->stream;
     // LSFC_DIST_OVERLAP=0: no overlap -- every exchange on the compute stream, chunk after chunk (debugging aid)
     if ((d->nranks == 1 && !d->force_overlap) || d->no_overlap) {
@@ -164,7 +167,7 @@ void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
 
 void dist_allreduce_sum(lsfc_plan* p, cplx* dev, int count) {
     DistState* d = p->dist.get();
-    if (!d || d->sim || (d->nranks == 1 && !d->force_comm)) return;
+    if (!d || d->sim || d->member || (d->nranks == 1 && !d->force_comm)) return;
     LSFC_NCCL(ncclAllReduce(dev, dev, (size_t)count * 2, ncclDouble, ncclSum, (ncclComm_t)d->comm, p->stream));
 }
 
@@ -175,7 +178,7 @@ void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y, std::function<voi
     const int K = d->K;
     // un-overlapped, stage by stage, all on the plan's stream (the production path overlaps the exchanges)
     add("xfwd", N * (C + 8) + 2 * N * C, [=] { phase1(p, x, true, st); });
-    const bool sim = d->sim;                                    // simulated rank: compute stages only (per-rank kernel times at P ranks)
+    const bool sim = d->sim || d->member;                       // simulated rank: compute stages only (per-rank kernel times at P ranks)
     if (!sim) add("alltoall_in", 2 * N * C, [=] { for (int c = 0; c < K; ++c) exchange(p, c, false, st); });
     add("yfwd", 6 * N * C, [=] { for (int c = 0; c < K; ++c) phase2_yfwd(p, c, st); });
     add("zfused", 16 * N * C, [=] { for (int c = 0; c < K; ++c) phase2_zfused(p, c, st); });
@@ -186,7 +189,7 @@ void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y, std::function<voi
 
 // ---------------------------------------------------------------------------
 static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega, const double* nu_local,
-                             unsigned flags, int device, int rank, int nranks, const unsigned char* id, bool sim) {
+                             unsigned flags, int device, int rank, int nranks, const unsigned char* id, bool sim, bool member = false) {
     LSFC_REQUIRE(out, "NULL argument"); *out = nullptr;
     LSFC_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
     LSFC_REQUIRE(n % 2 == 0 && m % 2 == 0 && l % 2 == 0, "even grid sizes only");
@@ -203,7 +206,7 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     for (int d = 0; d < 3; ++d) { p->pads[d] = pruned_best_length(p->dims[d]); p->crop[d] = 0; }
     p->dist.reset(new DistState());
     DistState* d = p->dist.get();
-    d->rank = rank; d->nranks = nranks; d->sim = sim; d->lz = lz; d->W = p->pads[0] / nranks;
+    d->rank = rank; d->nranks = nranks; d->sim = sim; d->member = member; d->lz = lz; d->W = p->pads[0] / nranks;
     // pipeline chunks: up to 4, each at least one 8-wide tile (LSFC_DIST_CHUNKS overrides; 1 disables the overlap)
     int K = 4;
     if (const char* v = getenv("LSFC_DIST_CHUNKS")) K = atoi(v);
@@ -217,8 +220,9 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     d->no_overlap = getenv("LSFC_DIST_OVERLAP") && getenv("LSFC_DIST_OVERLAP")[0] == '0';
     d->split_edges = !(getenv("LSFC_DIST_SPLIT_EDGES") && getenv("LSFC_DIST_SPLIT_EDGES")[0] == '0');
     // LSFC_DIST_FORCE_COMM=1: build the communicators and route the (self) exchange through RCCL even with one rank
-    d->force_comm = !sim && getenv("LSFC_DIST_FORCE_COMM") && getenv("LSFC_DIST_FORCE_COMM")[0] == '1';
-    if (!sim && (nranks > 1 || d->force_comm)) {
+    d->force_comm = !sim && !member && getenv("LSFC_DIST_FORCE_COMM") && getenv("LSFC_DIST_FORCE_COMM")[0] == '1';
+    if (member) d->force_overlap = false;               // the parent plan drives the streams of its ranks
+    if (!sim && !member && (nranks > 1 || d->force_comm)) {
         LSFC_REQUIRE(id, "NULL unique id");
         // an all-zero id means the caller never received rank 0's id (no broadcast happened): ncclCommInitRank would
         // block forever on every rank instead of failing
@@ -233,7 +237,7 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
         LSFC_NCCL(ncclCommSplit(comm, 0, rank, &comm2, nullptr));
         d->comm2 = comm2;
     }
-    if (!sim && (nranks > 1 || d->force_overlap)) {
+    if (!sim && (nranks > 1 || d->force_overlap || member)) {
         LSFC_HIP(hipStreamCreateWithFlags(&d->cs1, hipStreamNonBlocking));
         LSFC_HIP(hipStreamCreateWithFlags(&d->cs2, hipStreamNonBlocking));
         for (hipEvent_t* e : { &d->ev_p1, &d->ev_p1a, &d->ev_backa }) LSFC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -278,11 +282,324 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     *out = p.release();
 }
 
+
+// ---------------------------------------------------------------------------
+// Single-process multi-device plan: ONE host thread enqueues the work of all P ranks (one per device).  The schedule
+// is the three-stream pipeline of dist_convolve_dev, made explicit across devices with events (a stream of one device
+// may wait on an event of another).  Two transports for the slab exchanges:
+//   rccl  grouped ncclSend/ncclRecv over the communicators of ncclCommInitAll (distinct devices; the default)
+//   copy  hipMemcpyPeerAsync issued by the SOURCE rank on its communication stream (copy engines instead of CUs; also
+//         the only form that runs with a device listed twice, which is how the driver is tested on a one-GPU box)
+// ---------------------------------------------------------------------------
+MultiState::~MultiState() {
+    for (void* c : comm2) if (c) (void)ncclCommDestroy((ncclComm_t)c);
+    for (void* c : comm) if (c) (void)ncclCommDestroy((ncclComm_t)c);
+    if (red_pin) (void)hipHostFree(red_pin);
+}
+
+namespace {
+struct Multi {
+    lsfc_plan* root; MultiState* ms; int P, K;
+    explicit Multi(lsfc_plan* r) : root(r), ms(r->multi.get()), P(ms->P), K(ms->sub[0]->dist->K) {}
+    lsfc_plan* sub(int r) const { return ms->sub[(size_t)r].get(); }
+    DistState* d(int r) const { return sub(r)->dist.get(); }
+    void dev(int r) const { LSFC_HIP(hipSetDevice(ms->devices[(size_t)r])); }
+    hipStream_t st(int r) const { return sub(r)->stream; }
+    int64_t B() const { return block_elems(sub(0)); }
+
+    // Exchange of chunk c between all ranks.  `on`: 0 = the communication streams (cs1 way in, cs2 way back), 1 = the
+    // compute streams (per-stage profile).
+    void exchange(int c, bool back, int part, int on) const {
+        const int64_t Bfull = B(), Bp = part < 0 ? Bfull : Bfull / 2, off = part == 1 ? Bfull / 2 : 0;
+        auto s1 = [&](int r, int q) { return d(r)->S1.p + ((int64_t)q * K + c) * Bfull + off; };     // rank r's block for / from rank q
+        auto r1 = [&](int r, int q) { return d(r)->R1.p + ((int64_t)c * P + q) * Bfull + off; };     // rank r's slot of rank q
+        auto stream = [&](int r) { return on == 1 ? st(r) : (back ? d(r)->cs2 : d(r)->cs1); };
+        const size_t bytes = (size_t)Bp * sizeof(cplx);
+        if (!ms->rccl) {
+            for (int r = 0; r < P; ++r) {
+                dev(r);
+                for (int s = 0; s < P; ++s) {
+                    const int q = (r + s) % P;                  // every source starts with a different peer
+                    const cplx* src = back ? r1(r, q) : s1(r, q);
+                    cplx* dst = back ? s1(q, r) : r1(q, r);
+                    if (ms->devices[(size_t)q] == ms->devices[(size_t)r]) LSFC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream(r)));
+                    else LSFC_HIP(hipMemcpyPeerAsync(dst, ms->devices[(size_t)q], src, ms->devices[(size_t)r], bytes, stream(r)));
+                }
+            }
+            return;
+        }
+        for (int r = 0; r < P; ++r) {
+            dev(r);
+            LSFC_HIP(hipMemcpyAsync(back ? s1(r, r) : r1(r, r), back ? r1(r, r) : s1(r, r), bytes, hipMemcpyDeviceToDevice, stream(r)));
+        }
+        if (P == 1) return;
+        LSFC_NCCL(ncclGroupStart());
+        for (int r = 0; r < P; ++r) {
+            ncclComm_t comm = (ncclComm_t)(back ? ms->comm2[(size_t)r] : ms->comm[(size_t)r]);
+            for (int s = 1; s < P; ++s) {
+                const int to = (r + s) % P, from = (r - s + P) % P;
+                LSFC_NCCL(ncclSend(back ? r1(r, to) : s1(r, to), (size_t)Bp * 2, ncclDouble, to, comm, stream(r)));
+                LSFC_NCCL(ncclRecv(back ? s1(r, from) : r1(r, from), (size_t)Bp * 2, ncclDouble, from, comm, stream(r)));
+            }
+        }
+        LSFC_NCCL(ncclGroupEnd());
+    }
+    void wait_all(hipStream_t s, hipEvent_t DistState::* ev) const { for (int q = 0; q < P; ++q) LSFC_HIP(hipStreamWaitEvent(s, d(q)->*ev, 0)); }
+    void wait_all(hipStream_t s, std::vector<hipEvent_t> DistState::* ev, int c) const {
+        for (int q = 0; q < P; ++q) LSFC_HIP(hipStreamWaitEvent(s, (d(q)->*ev)[(size_t)c], 0));
+    }
+};
+} // namespace
+
+void multi_synchronize(lsfc_plan* root) {
+    Multi M(root);
+    for (int r = 0; r < M.P; ++r) { M.dev(r); LSFC_HIP(hipDeviceSynchronize()); }
+}
+
+void multi_convolve_dev(lsfc_plan* root, const cplx* const* x, cplx* const* y, bool use_nu, double alpha, double beta) {
+    Multi M(root);
+    const int P = M.P, K = M.K;
+    const bool overlap = !M.d(0)->no_overlap;
+    const bool edges = overlap && M.d(0)->split_edges && M.d(0)->lz % 2 == 0;
+    // phase 1 on every rank: k_xfwd, output packed per (destination rank, chunk)
+    for (int r = 0; r < P; ++r) {
+        M.dev(r);
+        if (edges) {
+            phase1(M.sub(r), x[r], use_nu, M.st(r), 0);
+            LSFC_HIP(hipEventRecord(M.d(r)->ev_p1a, M.st(r)));
+            phase1(M.sub(r), x[r], use_nu, M.st(r), 1);
+        } else phase1(M.sub(r), x[r], use_nu, M.st(r));
+        LSFC_HIP(hipEventRecord(M.d(r)->ev_p1, M.st(r)));
+    }
+    // way in.  A block may only land on rank q once q's previous apply has drained (its R1 / S1 are re-used): every
+    // communication stream waits for the x pass of EVERY rank, which on each rank follows the previous apply's last pass.
+    if (edges) {
+        for (int r = 0; r < P; ++r) { M.dev(r); M.wait_all(M.d(r)->cs1, &DistState::ev_p1a); }
+        M.exchange(0, false, 0, 0);
+    }
+    for (int r = 0; r < P; ++r) { M.dev(r); M.wait_all(M.d(r)->cs1, &DistState::ev_p1); M.wait_all(M.d(r)->cs2, &DistState::ev_p1); }
+    for (int c = 0; c < K; ++c) {
+        M.exchange(c, false, (edges && c == 0) ? 1 : -1, 0);
+        for (int r = 0; r < P; ++r) { M.dev(r); LSFC_HIP(hipEventRecord(M.d(r)->ev_in[(size_t)c], M.d(r)->cs1)); }
+    }
+    // y / z / y passes chunk by chunk; the way back of chunk c runs under the passes of chunk c + 1
+    for (int c = 0; c < K; ++c) {
+        for (int r = 0; r < P; ++r) {
+            M.dev(r);
+            M.wait_all(M.st(r), &DistState::ev_in, c);          // copy transport: every source signals its own blocks
+            phase2(M.sub(r), c, M.st(r));
+            LSFC_HIP(hipEventRecord(M.d(r)->ev_done[(size_t)c], M.st(r)));
+            LSFC_HIP(hipStreamWaitEvent(M.d(r)->cs2, M.d(r)->ev_done[(size_t)c], 0));
+        }
+        if (!overlap) for (int r = 0; r < P; ++r) { M.dev(r); LSFC_HIP(hipStreamSynchronize(M.st(r))); }
+        if (edges && c == K - 1) {
+            M.exchange(c, true, 0, 0);
+            for (int r = 0; r < P; ++r) { M.dev(r); LSFC_HIP(hipEventRecord(M.d(r)->ev_backa, M.d(r)->cs2)); }
+            M.exchange(c, true, 1, 0);
+        } else M.exchange(c, true, -1, 0);
+        for (int r = 0; r < P; ++r) { M.dev(r); LSFC_HIP(hipEventRecord(M.d(r)->ev_back[(size_t)c], M.d(r)->cs2)); }
+    }
+    // phase 3: k_xinv reads the packed blocks; rank r needs the blocks of every source (their cs2 streams run in order,
+    // so the event of the last chunk covers the earlier ones)
+    for (int r = 0; r < P; ++r) {
+        M.dev(r);
+        if (edges) {
+            M.wait_all(M.st(r), &DistState::ev_backa);
+            phase3(M.sub(r), x[r], y[r], alpha, beta, M.st(r), 0);
+            M.wait_all(M.st(r), &DistState::ev_back, K - 1);
+            phase3(M.sub(r), x[r], y[r], alpha, beta, M.st(r), 1);
+        } else {
+            M.wait_all(M.st(r), &DistState::ev_back, K - 1);
+            phase3(M.sub(r), x[r], y[r], alpha, beta, M.st(r));
+        }
+    }
+}
+
+void multi_convolve_host(lsfc_plan* root, const cplx* x, cplx* y, bool use_nu, double alpha, double beta) {
+    Multi M(root);
+    std::vector<const cplx*> xd((size_t)M.P); std::vector<cplx*> yd((size_t)M.P);
+    int64_t off = 0;
+    for (int r = 0; r < M.P; ++r) {
+        lsfc_plan* p = M.sub(r);
+        M.dev(r);
+        if (p->xs.n < (size_t)p->N) { p->xs.alloc((size_t)p->N); p->ys.alloc((size_t)p->N); }
+        LSFC_HIP(hipMemcpyAsync(p->xs.p, x + off, (size_t)p->N * sizeof(cplx), hipMemcpyHostToDevice, p->stream));
+        xd[(size_t)r] = p->xs.p; yd[(size_t)r] = p->ys.p; off += p->N;
+    }
+    multi_convolve_dev(root, xd.data(), yd.data(), use_nu, alpha, beta);
+    off = 0;
+    for (int r = 0; r < M.P; ++r) {
+        lsfc_plan* p = M.sub(r);
+        M.dev(r);
+        LSFC_HIP(hipMemcpyAsync(y + off, p->ys.p, (size_t)p->N * sizeof(cplx), hipMemcpyDeviceToHost, p->stream));
+        off += p->N;
+    }
+    for (int r = 0; r < M.P; ++r) { M.dev(r); LSFC_HIP(hipStreamSynchronize(M.st(r))); }
+}
+
+// sum over the ranks of `count` complex scalars held at dev[r] on devices[r]; the result replaces every copy
+void multi_allreduce_sum(lsfc_plan* root, cplx* const* dev, int count) {
+    Multi M(root);
+    if (M.P == 1) return;
+    if (M.ms->rccl) {
+        LSFC_NCCL(ncclGroupStart());
+        for (int r = 0; r < M.P; ++r)
+            LSFC_NCCL(ncclAllReduce(dev[r], dev[r], (size_t)count * 2, ncclDouble, ncclSum, (ncclComm_t)M.ms->comm[(size_t)r], M.st(r)));
+        LSFC_NCCL(ncclGroupEnd());
+        return;
+    }
+    // copy transport: O(restart) scalars through pinned host memory, summed in rank order (reproducible)
+    LSFC_REQUIRE(count <= 256, "internal: reduction of %d scalars", count);
+    cplx* pin = M.ms->red_pin;
+    for (int r = 0; r < M.P; ++r) { M.dev(r); LSFC_HIP(hipMemcpyAsync(pin + (size_t)(r + 1) * 256, dev[r], (size_t)count * sizeof(cplx), hipMemcpyDeviceToHost, M.st(r))); }
+    for (int r = 0; r < M.P; ++r) { M.dev(r); LSFC_HIP(hipStreamSynchronize(M.st(r))); }
+    for (int i = 0; i < count; ++i) {
+        cplx acc = make_double2(0.0, 0.0);
+        for (int r = 0; r < M.P; ++r) { acc.x += pin[(size_t)(r + 1) * 256 + i].x; acc.y += pin[(size_t)(r + 1) * 256 + i].y; }
+        pin[i] = acc;
+    }
+    for (int r = 0; r < M.P; ++r) { M.dev(r); LSFC_HIP(hipMemcpyAsync(dev[r], pin, (size_t)count * sizeof(cplx), hipMemcpyHostToDevice, M.st(r))); }
+}
+
+// per-stage timing of one apply on the ranks' staging vectors: every stage runs on all ranks, un-overlapped, with a
+// device-wide synchronisation in between; the time of a stage is the slowest rank's
+void multi_profile(lsfc_plan* root, int reps, int max_stages, const char** names, double* ms, double* bytes, int* nstages) {
+    Multi M(root);
+    const int P = M.P, K = M.K;
+    const double N = (double)M.sub(0)->N, C = 16.0, om2 = root->omega * root->omega;
+    for (int r = 0; r < P; ++r) {
+        lsfc_plan* p = M.sub(r);
+        M.dev(r);
+        if (p->xs.n < (size_t)p->N) { p->xs.alloc((size_t)p->N); p->ys.alloc((size_t)p->N); LSFC_HIP(hipMemset(p->xs.p, 0, p->xs.bytes())); }
+    }
+    struct Stage { const char* name; double bytes; std::function<void()> run; };
+    std::vector<Stage> stages;
+    auto each = [&M, P](std::function<void(int)> f) { return [&M, P, f] { for (int r = 0; r < P; ++r) { M.dev(r); f(r); } }; };
+    stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, each([&M](int r) { phase1(M.sub(r), M.sub(r)->xs.p, true, M.st(r)); })});
+    stages.push_back({"alltoall_in", 2 * N * C, [&M, K] { for (int c = 0; c < K; ++c) M.exchange(c, false, -1, 1); }});
+    stages.push_back({"yfwd", 6 * N * C, each([&M, K](int r) { for (int c = 0; c < K; ++c) phase2_yfwd(M.sub(r), c, M.st(r)); })});
+    stages.push_back({"zfused", 16 * N * C, each([&M, K](int r) { for (int c = 0; c < K; ++c) phase2_zfused(M.sub(r), c, M.st(r)); })});
+    stages.push_back({"yinv", 6 * N * C, each([&M, K](int r) { for (int c = 0; c < K; ++c) phase2_yinv(M.sub(r), c, M.st(r)); })});
+    stages.push_back({"alltoall_back", 2 * N * C, [&M, K] { for (int c = 0; c < K; ++c) M.exchange(c, true, -1, 1); }});
+    stages.push_back({"xinv", 4 * N * C, each([&M, om2](int r) { phase3(M.sub(r), M.sub(r)->xs.p, M.sub(r)->ys.p, 1.0, om2, M.st(r)); })});
+    LSFC_REQUIRE((int)stages.size() <= max_stages, "max_stages too small (need %d)", (int)stages.size());
+    *nstages = (int)stages.size();
+    std::vector<hipEvent_t> e0((size_t)P), e1((size_t)P);
+    for (int r = 0; r < P; ++r) { M.dev(r); LSFC_HIP(hipEventCreate(&e0[(size_t)r])); LSFC_HIP(hipEventCreate(&e1[(size_t)r])); }
+    for (size_t i = 0; i < stages.size(); ++i) { names[i] = stages[i].name; bytes[i] = stages[i].bytes; ms[i] = 0.0; }
+    for (int rep = 0; rep < reps; ++rep)
+        for (size_t i = 0; i < stages.size(); ++i) {
+            multi_synchronize(root);
+            for (int r = 0; r < P; ++r) { M.dev(r); LSFC_HIP(hipEventRecord(e0[(size_t)r], M.st(r))); }
+            stages[i].run();
+            for (int r = 0; r < P; ++r) { M.dev(r); LSFC_HIP(hipEventRecord(e1[(size_t)r], M.st(r))); }
+            multi_synchronize(root);
+            float worst = 0;
+            for (int r = 0; r < P; ++r) { float t = 0; LSFC_HIP(hipEventElapsedTime(&t, e0[(size_t)r], e1[(size_t)r])); worst = std::max(worst, t); }
+            ms[i] += worst;
+        }
+    for (size_t i = 0; i < stages.size(); ++i) ms[i] /= reps;
+    for (int r = 0; r < P; ++r) { (void)hipEventDestroy(e0[(size_t)r]); (void)hipEventDestroy(e1[(size_t)r]); }
+}
+
+static void create_multi_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega, const double* nu,
+                              unsigned flags, const int* devices, int ndev) {
+    LSFC_REQUIRE(out, "NULL argument"); *out = nullptr;
+    LSFC_REQUIRE(devices && ndev >= 1 && ndev <= 64, "devices[] / ndev: need 1..64 devices");
+    LSFC_REQUIRE(nu, "nu is NULL");
+    LSFC_REQUIRE(l % ndev == 0, "l = %lld is not divisible by the number of devices %d", (long long)l, ndev);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) fail(LSFC_ENODEV, "no HIP device available: the lsfc operator has no CPU fallback");
+    bool distinct = true;
+    for (int r = 0; r < ndev; ++r) {
+        LSFC_REQUIRE(devices[r] >= 0 && devices[r] < count, "device %d out of range (have %d)", devices[r], count);
+        for (int q = 0; q < r; ++q) if (devices[q] == devices[r]) distinct = false;
+    }
+    std::unique_ptr<lsfc_plan> root(new lsfc_plan());
+    root->device = devices[0]; root->ndim = 3;
+    root->dims[0] = (int)n; root->dims[1] = (int)m; root->dims[2] = (int)l;
+    root->N = n * m * l; root->omega = omega; root->quad_rule = LSFC_QUAD_GREENGARD_VICO; root->flags = flags;
+    root->pipeline = lsfc_plan::PRUNED;
+    root->multi.reset(new MultiState());
+    MultiState* ms = root->multi.get();
+    ms->P = ndev; ms->devices.assign(devices, devices + ndev);
+    // transport: RCCL whenever the devices are distinct (LSFC_MULTI_TRANSPORT=copy selects the copy engines instead);
+    // a device listed more than once (tests on a one-GPU box) can only use copies
+    const char* tr = getenv("LSFC_MULTI_TRANSPORT");
+    ms->rccl = distinct && !(tr && std::string(tr) == "copy");
+    LSFC_REQUIRE(distinct || !(tr && std::string(tr) == "rccl"), "LSFC_MULTI_TRANSPORT=rccl needs distinct devices");
+    // the ranks are built concurrently, one helper thread per device (symbol evaluation + rocFFT plan compilation are
+    // the long part); ranks that share a device are built one after the other
+    const int64_t nloc = n * m * (l / ndev);
+    ms->sub.resize((size_t)ndev);
+    std::vector<int> rc((size_t)ndev, LSFC_OK); std::vector<std::string> msg((size_t)ndev);
+    auto build = [&](int r) {
+        lsfc_plan* sp = nullptr;
+        rc[(size_t)r] = guarded([&] { create_dist_plan(&sp, n, m, l, box, omega, nu + (int64_t)r * nloc, flags, devices[r], r, ndev, nullptr, false, true); });
+        if (rc[(size_t)r] != LSFC_OK) msg[(size_t)r] = lsfc_last_error();
+        ms->sub[(size_t)r].reset(sp);
+    };
+    if (distinct && ndev > 1) {
+        std::vector<std::thread> th;
+        for (int r = 0; r < ndev; ++r) th.emplace_back(build, r);
+        for (auto& t : th) t.join();
+    } else for (int r = 0; r < ndev; ++r) build(r);
+    for (int r = 0; r < ndev; ++r) if (rc[(size_t)r] != LSFC_OK) fail(rc[(size_t)r], "rank %d on device %d: %s", r, devices[r], msg[(size_t)r].c_str());
+    for (int d = 0; d < 3; ++d) root->pads[d] = ms->sub[0]->pads[d];
+    if (distinct && ndev > 1) {
+        // peer access for the copy transport (and for RCCL's own P2P paths)
+        for (int r = 0; r < ndev; ++r) {
+            LSFC_HIP(hipSetDevice(devices[r]));
+            for (int q = 0; q < ndev; ++q) if (q != r) {
+                int can = 0; LSFC_HIP(hipDeviceCanAccessPeer(&can, devices[r], devices[q]));
+                if (can) { hipError_t pe = hipDeviceEnablePeerAccess(devices[q], 0); if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) LSFC_HIP(pe); (void)hipGetLastError(); }
+                else LSFC_REQUIRE(ms->rccl, "device %d cannot access device %d: the copy transport needs peer access", devices[r], devices[q]);
+            }
+        }
+    }
+    if (ms->rccl && ndev > 1) {
+        std::vector<ncclComm_t> c1((size_t)ndev), c2((size_t)ndev);
+        LSFC_NCCL(ncclCommInitAll(c1.data(), ndev, devices));
+        ms->comm.assign(c1.begin(), c1.end());
+        LSFC_NCCL(ncclCommInitAll(c2.data(), ndev, devices));
+        ms->comm2.assign(c2.begin(), c2.end());
+    } else ms->rccl = ms->rccl && ndev > 1;
+    LSFC_HIP(hipSetDevice(devices[0]));
+    LSFC_HIP(hipHostMalloc((void**)&ms->red_pin, (size_t)(ndev + 1) * 256 * sizeof(cplx)));
+    *out = root.release();
+}
+
 } // namespace lsfc
 
 using namespace lsfc;
 
 extern "C" {
+
+int lsfc_plan_create_gv3d_multi(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega, const double* nu,
+                                unsigned flags, const int* devices, int ndev) {
+    return guarded([&] { create_multi_plan(out, n, m, l, box, omega, nu, flags, devices, ndev); });
+}
+
+int lsfc_multi_info(const lsfc_plan* plan, int* ndev, int* devices, int64_t* local_n, const char** transport) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan && plan->multi, "not a multi-device plan");
+        const MultiState* ms = plan->multi.get();
+        if (ndev) *ndev = ms->P;
+        if (devices) for (int r = 0; r < ms->P; ++r) devices[r] = ms->devices[(size_t)r];
+        if (local_n) *local_n = ms->sub[0]->N;
+        if (transport) *transport = ms->P == 1 ? "none (one device)" : (ms->rccl ? "rccl send/recv (ncclCommInitAll), pairwise schedule" : "peer copies (hipMemcpyPeerAsync), source-issued");
+    });
+}
+
+int lsfc_multi_apply_dev(lsfc_plan* plan, const double* const* x_dev, double* const* y_dev, int mode) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan && plan->multi && x_dev && y_dev, "not a multi-device plan / NULL argument");
+        LSFC_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (apply), 1 (convolve) or 2 (convolve with nu)");
+        const double om2 = plan->omega * plan->omega;
+        multi_convolve_dev(plan, (const cplx* const*)x_dev, (cplx* const*)y_dev, mode != 1, mode == 0 ? 1.0 : 0.0, mode == 0 ? om2 : 1.0);
+    });
+}
 
 int lsfc_dist_unique_id(unsigned char id[LSFC_UNIQUE_ID_BYTES]) {
     return guarded([&] {

@@ -8,6 +8,7 @@
 #include "pointwise.hpp"
 #include <cmath>
 #include <complex>
+#include <functional>
 #include <vector>
 
 namespace lsfc {
@@ -19,17 +20,20 @@ GmresWorkspace::~GmresWorkspace() {
     if (vpin) (void)hipHostFree(vpin);
 }
 
-static GmresWorkspace* workspace(lsfc_plan* p, int restart, bool need_vpin) {
-    if (!p->gmres || p->gmres->restart < restart) {
+// vectors = false: only the pinned host vector (the root of a multi-device plan, whose Krylov basis lives in its ranks)
+static GmresWorkspace* workspace(lsfc_plan* p, int restart, bool need_vpin, bool vectors = true) {
+    if (!p->gmres || (vectors && p->gmres->restart < restart)) {
         p->gmres.reset(new GmresWorkspace());
         GmresWorkspace* w = p->gmres.get();
-        w->restart = restart;
-        w->V.alloc((size_t)(restart + 1) * (size_t)p->N);
-        w->hdev.alloc((size_t)restart + 2);
-        w->ydev.alloc((size_t)restart + 2);
-        w->partial.alloc((size_t)blas_partial_count());
-        w->ax.alloc((size_t)p->N);
-        LSFC_HIP(hipHostMalloc((void**)&w->hpin, ((size_t)restart + 2) * sizeof(cplx)));
+        if (vectors) {
+            w->restart = restart;
+            w->V.alloc((size_t)(restart + 1) * (size_t)p->N);
+            w->hdev.alloc((size_t)restart + 2);
+            w->ydev.alloc((size_t)restart + 2);
+            w->partial.alloc((size_t)blas_partial_count());
+            w->ax.alloc((size_t)p->N);
+            LSFC_HIP(hipHostMalloc((void**)&w->hpin, ((size_t)restart + 2) * sizeof(cplx)));
+        }
     }
     if (need_vpin && !p->gmres->vpin) LSFC_HIP(hipHostMalloc((void**)&p->gmres->vpin, (size_t)p->N * sizeof(cplx)));
     return p->gmres.get();
@@ -71,54 +75,108 @@ static void solve_least_squares(const std::vector<zc>& H, int ldh, double beta, 
     }
 }
 
-void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap, lsfc_gmres_result* res) {
-    lsfc_gmres_opts o;
-    if (opts_in) o = *opts_in; else { o.restart = 0; o.maxiter = 0; o.reltol = -1; o.abstol = 0; o.orth = LSFC_ORTH_MGS; o.initially_zero = 0; o.precond = nullptr; o.precond_user = nullptr; o.precond_on_device = 0; }
-    const int64_t N = p->N;
-    const int restart = (int)(o.restart > 0 ? o.restart : std::min<int64_t>(20, N));
-    const int64_t maxiter = o.maxiter > 0 ? o.maxiter : N;
-    const double reltol = o.reltol >= 0 ? o.reltol : std::sqrt(2.220446049250313e-16);
-    const double abstol = o.abstol > 0 ? o.abstol : 0.0;
-    LSFC_REQUIRE(o.orth == LSFC_ORTH_MGS || o.orth == LSFC_ORTH_CGS || o.orth == LSFC_ORTH_DGKS, "unknown orthogonalisation %d", o.orth);
-    LSFC_REQUIRE(restart >= 1, "restart must be >= 1");
+// The solver is written once over a TEAM of members, each holding one slab of every vector on its own device:
+//   one member   ordinary plans, and one rank of a multi-PROCESS slab plan (inner products completed by ncclAllReduce)
+//   P members    the ranks of a single-process multi-DEVICE plan, all driven from the calling thread
+// Every vector operation is enqueued member by member; the O(restart) scalars of a step are identical on all members
+// after the reduction and are read back from member 0.
+namespace {
+struct Member { lsfc_plan* p; GmresWorkspace* w; cplx* x; const cplx* b; };
 
-    GmresWorkspace* w = workspace(p, restart, o.precond != nullptr && !o.precond_on_device);
-    hipStream_t st = p->stream;
-    auto Vcol = [&](int j) { return w->V.p + (size_t)j * (size_t)N; };
-    // slab-distributed plan: every inner product / squared norm is completed by an all-reduce over the ranks
-    const bool multi = p->dist && !p->dist->sim && (p->dist->nranks > 1 || p->dist->force_comm);
-    auto finish_dot = [&](cplx* s, int count) { if (multi) dist_allreduce_sum(p, s, count); };
-    auto finish_nrm = [&](cplx* s) { if (multi) { dist_allreduce_sum(p, s, 1); blas_sqrt_dev(s, st); } };
+struct Team {
+    lsfc_plan* root;
+    std::vector<Member> mem;
+    bool reduce = false;                // local inner products are partial sums
+    GmresWorkspace* rootw = nullptr;    // pinned host vector of the preconditioner callback
 
-    auto precondition = [&](cplx* v) {
+    static void dev(const Member& m) { LSFC_HIP(hipSetDevice(m.p->device)); }
+    static cplx* V(const Member& m, int j) { return m.w->V.p + (size_t)j * (size_t)m.p->N; }
+    template <class F> void each(F&& f) { for (auto& m : mem) { dev(m); f(m); } }
+
+    void apply(const std::function<const cplx*(const Member&)>& in, const std::function<cplx*(const Member&)>& out) {
+        if (!root->multi) { dev(mem[0]); plan_apply_dev(root, in(mem[0]), out(mem[0])); return; }
+        std::vector<const cplx*> xi; std::vector<cplx*> yo;
+        for (auto& m : mem) { xi.push_back(in(m)); yo.push_back(out(m)); }
+        multi_convolve_dev(root, xi.data(), yo.data(), true, 1.0, root->omega * root->omega);
+    }
+    void allreduce(int off, int count) {
+        if (!reduce) return;
+        if (!root->multi) { dev(mem[0]); dist_allreduce_sum(root, mem[0].w->hdev.p + off, count); return; }
+        std::vector<cplx*> ptr;
+        for (auto& m : mem) ptr.push_back(m.w->hdev.p + off);
+        multi_allreduce_sum(root, ptr.data(), count);
+    }
+    void finish_nrm(int off) {
+        if (!reduce) return;
+        allreduce(off, 1);
+        each([&](Member& m) { blas_sqrt_dev(m.w->hdev.p + off, m.p->stream); });
+    }
+    // scalars of the step -> pinned host memory of member 0
+    void fetch_h(int count) {
+        Member& m = mem[0];
+        dev(m);
+        LSFC_HIP(hipMemcpyAsync(m.w->hpin, m.w->hdev.p, (size_t)count * sizeof(cplx), hipMemcpyDeviceToHost, m.p->stream));
+        LSFC_HIP(hipStreamSynchronize(m.p->stream));
+    }
+    cplx* hpin() { return mem[0].w->hpin; }
+    void sync() { each([](Member& m) { LSFC_HIP(hipStreamSynchronize(m.p->stream)); }); }
+};
+
+void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap, lsfc_gmres_result* res, int restart,
+           int64_t maxiter, double reltol, double abstol, const lsfc_gmres_opts& o) {
+    const int64_t Ntot = T.root->N;
+
+    auto precondition = [&](int col) {
         if (!o.precond) return;
         if (o.precond_on_device) {
-            const int rc = o.precond(o.precond_user, (double*)v, N);
+            LSFC_REQUIRE(T.mem.size() == 1, "a device-resident preconditioner callback needs a single-device plan");
+            const int rc = o.precond(o.precond_user, (double*)Team::V(T.mem[0], col), T.mem[0].p->N);
             if (rc != 0) fail(LSFC_EINVAL, "preconditioner callback returned %d", rc);
             return;
         }
-        LSFC_HIP(hipMemcpyAsync(w->vpin, v, (size_t)N * sizeof(cplx), hipMemcpyDeviceToHost, st));
-        LSFC_HIP(hipStreamSynchronize(st));
-        const int rc = o.precond(o.precond_user, (double*)w->vpin, N);
+        // host callback, in place on the whole vector (the two-argument ldiv!): gather the slabs, call, scatter
+        cplx* vpin = T.rootw->vpin;
+        int64_t off = 0;
+        T.each([&](Member& m) { LSFC_HIP(hipMemcpyAsync(vpin + off, Team::V(m, col), (size_t)m.p->N * sizeof(cplx), hipMemcpyDeviceToHost, m.p->stream)); off += m.p->N; });
+        T.sync();
+        const int rc = o.precond(o.precond_user, (double*)vpin, T.mem.size() == 1 ? T.mem[0].p->N : Ntot);
         if (rc != 0) fail(LSFC_EINVAL, "preconditioner callback returned %d", rc);
-        LSFC_HIP(hipMemcpyAsync(v, w->vpin, (size_t)N * sizeof(cplx), hipMemcpyHostToDevice, st));
-    };
-    auto fetch_h = [&](int count) {
-        LSFC_HIP(hipMemcpyAsync(w->hpin, w->hdev.p, (size_t)count * sizeof(cplx), hipMemcpyDeviceToHost, st));
-        LSFC_HIP(hipStreamSynchronize(st));
+        off = 0;
+        T.each([&](Member& m) { LSFC_HIP(hipMemcpyAsync(Team::V(m, col), vpin + off, (size_t)m.p->N * sizeof(cplx), hipMemcpyHostToDevice, m.p->stream)); off += m.p->N; });
     };
 
     // init!: V1 = Pl \ (b - A x) normalised, returns beta
     auto init = [&](bool skip_mv) -> double {
-        cplx* v0 = Vcol(0);
-        if (skip_mv) LSFC_HIP(hipMemcpyAsync(v0, b, (size_t)N * sizeof(cplx), hipMemcpyDeviceToDevice, st));
-        else { plan_apply_dev(p, x, w->ax.p); blas_sub(v0, b, w->ax.p, N, st); }
-        precondition(v0);
-        blas_nrm2(v0, w->partial.p, w->hdev.p, N, st, multi);
-        finish_nrm(w->hdev.p);
-        blas_scale_inv_dev(v0, w->hdev.p, N, st);
-        fetch_h(1);
-        return w->hpin[0].x;
+        if (skip_mv) T.each([&](Member& m) { LSFC_HIP(hipMemcpyAsync(Team::V(m, 0), m.b, (size_t)m.p->N * sizeof(cplx), hipMemcpyDeviceToDevice, m.p->stream)); });
+        else {
+            T.apply([](const Member& m) { return (const cplx*)m.x; }, [](const Member& m) { return m.w->ax.p; });
+            T.each([&](Member& m) { blas_sub(Team::V(m, 0), m.b, m.w->ax.p, m.p->N, m.p->stream); });
+        }
+        precondition(0);
+        T.each([&](Member& m) { blas_nrm2(Team::V(m, 0), m.w->partial.p, m.w->hdev.p, m.p->N, m.p->stream, T.reduce); });
+        T.finish_nrm(0);
+        T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, 0), m.w->hdev.p, m.p->N, m.p->stream); });
+        T.fetch_h(1);
+        return T.hpin()[0].x;
+    };
+    // h[j0..j0+k) = V[:, 0..k)' w  and  w -= V h   (classical Gram-Schmidt sweep over the first k columns), then ||w||
+    auto cgs_sweep = [&](int k) {
+        T.each([&](Member& m) {
+            for (int j0 = 0; j0 < k; j0 += 64) {
+                const int kc = std::min(64, k - j0);
+                blas_multidot(Team::V(m, j0), m.p->N, kc, Team::V(m, k), m.w->partial.p, m.w->hdev.p + j0, m.p->N, m.p->stream);
+            }
+        });
+        T.allreduce(0, k);
+        T.each([&](Member& m) {
+            for (int j0 = 0; j0 < k; j0 += 64) {
+                const int kc = std::min(64, k - j0);
+                blas_gemv_acc(Team::V(m, k), Team::V(m, j0), m.p->N, kc, m.w->hdev.p + j0, -1.0, m.p->N, m.p->stream);
+            }
+            blas_nrm2(Team::V(m, k), m.w->partial.p, m.w->hdev.p + k, m.p->N, m.p->stream, T.reduce);
+        });
+        T.finish_nrm(k);
+        T.fetch_h(k + 1);
     };
 
     std::vector<zc> H((size_t)(restart + 1) * restart, zc(0));
@@ -133,71 +191,53 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
     std::vector<zc> y;
 
     while (!(iteration >= maxiter || current <= tol)) {
-        cplx* wv = Vcol(k);
-        plan_apply_dev(p, Vcol(k - 1), wv);            // expand!: V[:,k+1] = A V[:,k]
-        precondition(wv);                              //          ldiv!(Pl, V[:,k+1])
+        // expand!: V[:,k+1] = A V[:,k], then ldiv!(Pl, V[:,k+1])
+        T.apply([k](const Member& m) { return (const cplx*)Team::V(m, k - 1); }, [k](const Member& m) { return Team::V(m, k); });
+        precondition(k);
         ++mvps;
         double nrm;
+        cplx* hp = T.hpin();
         if (o.orth == LSFC_ORTH_MGS) {
             // h_i = <V_i, w>; w -= h_i V_i, each sweep fused with the next inner product (norm after the last)
-            blas_dot(Vcol(0), wv, w->partial.p, w->hdev.p, N, st);
-            finish_dot(w->hdev.p, 1);
+            T.each([&](Member& m) { blas_dot(Team::V(m, 0), Team::V(m, k), m.w->partial.p, m.w->hdev.p, m.p->N, m.p->stream); });
+            T.allreduce(0, 1);
             for (int i = 0; i < k; ++i) {
-                blas_axpy_dot(wv, Vcol(i), w->hdev.p + i, (i + 1 < k) ? Vcol(i + 1) : nullptr, w->partial.p, w->hdev.p + i + 1, N, st, multi);
-                if (i + 1 < k) finish_dot(w->hdev.p + i + 1, 1); else finish_nrm(w->hdev.p + i + 1);
+                T.each([&](Member& m) {
+                    blas_axpy_dot(Team::V(m, k), Team::V(m, i), m.w->hdev.p + i, (i + 1 < k) ? Team::V(m, i + 1) : nullptr, m.w->partial.p,
+                                  m.w->hdev.p + i + 1, m.p->N, m.p->stream, T.reduce);
+                });
+                if (i + 1 < k) T.allreduce(i + 1, 1); else T.finish_nrm(i + 1);
             }
-            blas_scale_inv_dev(wv, w->hdev.p + k, N, st);
-            fetch_h(k + 1);
-            nrm = w->hpin[k].x;
+            T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, k), m.w->hdev.p + k, m.p->N, m.p->stream); });
+            T.fetch_h(k + 1);
+            nrm = hp[k].x;
         } else {
-            for (int j0 = 0; j0 < k; j0 += 64) {
-                const int kc = std::min(64, k - j0);
-                blas_multidot(Vcol(j0), N, kc, wv, w->partial.p, w->hdev.p + j0, N, st);
-            }
-            finish_dot(w->hdev.p, k);
-            for (int j0 = 0; j0 < k; j0 += 64) {
-                const int kc = std::min(64, k - j0);
-                blas_gemv_acc(wv, Vcol(j0), N, kc, w->hdev.p + j0, -1.0, N, st);
-            }
-            blas_nrm2(wv, w->partial.p, w->hdev.p + k, N, st, multi);
-            finish_nrm(w->hdev.p + k);
-            fetch_h(k + 1);
-            nrm = w->hpin[k].x;
+            cgs_sweep(k);
+            nrm = hp[k].x;
             if (o.orth == LSFC_ORTH_DGKS) {
                 // IterativeSolvers orthogonalize.jl: `while nrm < projection_size / sqrt(2)`, projection_size being
                 // the norm of the latest correction; the corrections accumulate into the Hessenberg column
                 double proj = 0.0;
-                for (int i = 0; i < k; ++i) proj += w->hpin[i].x * w->hpin[i].x + w->hpin[i].y * w->hpin[i].y;
+                for (int i = 0; i < k; ++i) proj += hp[i].x * hp[i].x + hp[i].y * hp[i].y;
                 proj = std::sqrt(proj);
-                std::vector<cplx> hsum(w->hpin, w->hpin + k);
+                std::vector<cplx> hsum(hp, hp + k);
                 bool again = false;
-                for (int pass = 0; nrm < proj / std::sqrt(2.0) && pass < 8; ++pass) {     // (8: guard against a NaN-free but stagnating loop)
+                for (int pass = 0; nrm < proj / std::sqrt(2.0) && pass < 8; ++pass) {     // (8: guard against a stagnating loop)
                     again = true;
-                    for (int j0 = 0; j0 < k; j0 += 64) {
-                        const int kc = std::min(64, k - j0);
-                        blas_multidot(Vcol(j0), N, kc, wv, w->partial.p, w->hdev.p + j0, N, st);
-                    }
-                    finish_dot(w->hdev.p, k);
-                    for (int j0 = 0; j0 < k; j0 += 64) {
-                        const int kc = std::min(64, k - j0);
-                        blas_gemv_acc(wv, Vcol(j0), N, kc, w->hdev.p + j0, -1.0, N, st);
-                    }
-                    blas_nrm2(wv, w->partial.p, w->hdev.p + k, N, st, multi);
-                    finish_nrm(w->hdev.p + k);
-                    fetch_h(k + 1);
+                    cgs_sweep(k);
                     proj = 0.0;
                     for (int i = 0; i < k; ++i) {
-                        proj += w->hpin[i].x * w->hpin[i].x + w->hpin[i].y * w->hpin[i].y;
-                        hsum[i].x += w->hpin[i].x; hsum[i].y += w->hpin[i].y;
+                        proj += hp[i].x * hp[i].x + hp[i].y * hp[i].y;
+                        hsum[(size_t)i].x += hp[i].x; hsum[(size_t)i].y += hp[i].y;
                     }
                     proj = std::sqrt(proj);
-                    nrm = w->hpin[k].x;
+                    nrm = hp[k].x;
                 }
-                if (again) for (int i = 0; i < k; ++i) w->hpin[i] = hsum[i];
+                if (again) for (int i = 0; i < k; ++i) hp[i] = hsum[(size_t)i];
             }
-            blas_scale_inv_dev(wv, w->hdev.p + k, N, st);
+            T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, k), m.w->hdev.p + k, m.p->N, m.p->stream); });
         }
-        for (int i = 0; i < k; ++i) H[i + (size_t)ldh * (k - 1)] = zc(w->hpin[i].x, w->hpin[i].y);
+        for (int i = 0; i < k; ++i) H[i + (size_t)ldh * (k - 1)] = zc(hp[i].x, hp[i].y);
         H[k + (size_t)ldh * (k - 1)] = nrm;
 
         // update_residual!: nullvec[k+1] = -conj(dot(nullvec[1:k], H[1:k,k]) / H[k+1,k])
@@ -210,13 +250,16 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
 
         if (k == restart + 1 || current <= tol) {
             solve_least_squares(H, ldh, beta, k, y);
-            for (int i = 0; i < k - 1; ++i) w->hpin[i] = make_double2(y[i].real(), y[i].imag());
-            LSFC_HIP(hipMemcpyAsync(w->ydev.p, w->hpin, (size_t)(k - 1) * sizeof(cplx), hipMemcpyHostToDevice, st));
-            for (int j0 = 0; j0 < k - 1; j0 += 64) {
-                const int kc = std::min(64, k - 1 - j0);
-                blas_gemv_acc(x, Vcol(j0), N, kc, w->ydev.p + j0, +1.0, N, st);      // x += V y
-            }
-            LSFC_HIP(hipStreamSynchronize(st));
+            T.sync();                                       // (members other than 0 may still read their pinned scalars)
+            T.each([&](Member& m) {
+                for (int i = 0; i < k - 1; ++i) m.w->hpin[i] = make_double2(y[i].real(), y[i].imag());
+                LSFC_HIP(hipMemcpyAsync(m.w->ydev.p, m.w->hpin, (size_t)(k - 1) * sizeof(cplx), hipMemcpyHostToDevice, m.p->stream));
+                for (int j0 = 0; j0 < k - 1; j0 += 64) {
+                    const int kc = std::min(64, k - 1 - j0);
+                    blas_gemv_acc(m.x, Team::V(m, j0), m.p->N, kc, m.w->ydev.p + j0, +1.0, m.p->N, m.p->stream);      // x += V y
+                }
+            });
+            T.sync();
             k = 1;
             if (!(current <= tol)) {
                 beta = init(false);
@@ -228,8 +271,65 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
         if (resnorm && iteration < cap) resnorm[iteration] = current;
         ++iteration;
     }
-    LSFC_HIP(hipStreamSynchronize(st));
+    T.sync();
     res->iters = iteration; res->mvps = mvps; res->converged = current <= tol ? 1 : 0; res->final_resnorm = current;
+    (void)opts_in;
+}
+
+struct Resolved { lsfc_gmres_opts o; int restart; int64_t maxiter; double reltol, abstol; };
+Resolved resolve(const lsfc_gmres_opts* opts_in, int64_t N) {
+    Resolved r;
+    if (opts_in) r.o = *opts_in;
+    else { r.o.restart = 0; r.o.maxiter = 0; r.o.reltol = -1; r.o.abstol = 0; r.o.orth = LSFC_ORTH_MGS; r.o.initially_zero = 0; r.o.precond = nullptr; r.o.precond_user = nullptr; r.o.precond_on_device = 0; }
+    r.restart = (int)(r.o.restart > 0 ? r.o.restart : std::min<int64_t>(20, N));
+    r.maxiter = r.o.maxiter > 0 ? r.o.maxiter : N;
+    r.reltol = r.o.reltol >= 0 ? r.o.reltol : std::sqrt(2.220446049250313e-16);
+    r.abstol = r.o.abstol > 0 ? r.o.abstol : 0.0;
+    LSFC_REQUIRE(r.o.orth == LSFC_ORTH_MGS || r.o.orth == LSFC_ORTH_CGS || r.o.orth == LSFC_ORTH_DGKS, "unknown orthogonalisation %d", r.o.orth);
+    LSFC_REQUIRE(r.restart >= 1, "restart must be >= 1");
+    return r;
+}
+} // namespace
+
+void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap, lsfc_gmres_result* res) {
+    const Resolved r = resolve(opts_in, p->N);
+    Team T; T.root = p;
+    GmresWorkspace* w = workspace(p, r.restart, r.o.precond != nullptr && !r.o.precond_on_device);
+    T.mem.push_back({p, w, x, b});
+    T.rootw = w;
+    // slab-distributed plan (one process per GPU): every inner product / squared norm is completed by an all-reduce over the ranks
+    T.reduce = p->dist && !p->dist->sim && !p->dist->member && (p->dist->nranks > 1 || p->dist->force_comm);
+    solve(T, opts_in, resnorm, cap, res, r.restart, r.maxiter, r.reltol, r.abstol, r.o);
+}
+
+void gmres_run_multi(lsfc_plan* root, cplx* x_host, const cplx* b_host, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap,
+                     lsfc_gmres_result* res) {
+    LSFC_REQUIRE(root->multi, "not a multi-device plan");
+    const Resolved r = resolve(opts_in, root->N);
+    LSFC_REQUIRE(!(r.o.precond && r.o.precond_on_device), "a multi-device plan takes a host preconditioner callback");
+    Team T; T.root = root;
+    T.rootw = workspace(root, r.restart, r.o.precond != nullptr, false);
+    T.reduce = root->multi->P > 1;
+    int64_t off = 0;
+    for (auto& sp : root->multi->sub) {
+        lsfc_plan* p = sp.get();
+        LSFC_HIP(hipSetDevice(p->device));
+        GmresWorkspace* w = workspace(p, r.restart, false);
+        if (p->xs.n < (size_t)p->N) { p->xs.alloc((size_t)p->N); p->ys.alloc((size_t)p->N); }
+        LSFC_HIP(hipMemcpyAsync(p->xs.p, x_host + off, (size_t)p->N * sizeof(cplx), hipMemcpyHostToDevice, p->stream));
+        LSFC_HIP(hipMemcpyAsync(p->ys.p, b_host + off, (size_t)p->N * sizeof(cplx), hipMemcpyHostToDevice, p->stream));
+        T.mem.push_back({p, w, p->xs.p, p->ys.p});
+        off += p->N;
+    }
+    solve(T, opts_in, resnorm, cap, res, r.restart, r.maxiter, r.reltol, r.abstol, r.o);
+    off = 0;
+    for (auto& m : T.mem) {
+        Team::dev(m);
+        LSFC_HIP(hipMemcpyAsync(x_host + off, m.x, (size_t)m.p->N * sizeof(cplx), hipMemcpyDeviceToHost, m.p->stream));
+        off += m.p->N;
+    }
+    T.sync();
+    LSFC_HIP(hipSetDevice(root->device));
 }
 
 } // namespace lsfc

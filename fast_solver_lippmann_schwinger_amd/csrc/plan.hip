@@ -335,6 +335,12 @@ static void ensure_staging(lsfc_plan* p, int64_t count) {
 static void convolve_any(lsfc_plan* p, const double* x, double* y, int64_t nrhs, bool use_nu, double alpha, double beta, int memspace) {
     LSFC_REQUIRE(p && x && y, "NULL argument");
     LSFC_REQUIRE(nrhs >= 1, "nrhs must be >= 1");
+    if (p->multi) {
+        // one host process, several devices: the vector is scattered over the ranks' z-slabs, applied, gathered
+        LSFC_REQUIRE(memspace == LSFC_MEM_HOST, "a multi-device plan takes host vectors here; per-device slabs go through lsfc_multi_apply_dev");
+        for (int64_t j = 0; j < nrhs; ++j) multi_convolve_host(p, (const cplx*)x + j * p->N, (cplx*)y + j * p->N, use_nu, alpha, beta);
+        return;
+    }
     LSFC_HIP(hipSetDevice(p->device));
     if (memspace == LSFC_MEM_DEVICE) {
         for (int64_t j = 0; j < nrhs; ++j)
@@ -461,7 +467,12 @@ int lsfc_plan_create_trap2d(lsfc_plan** out, int64_t n, int64_t m, double x0, do
 }
 
 int lsfc_plan_destroy(lsfc_plan* plan) {
-    return guarded([&] { if (plan) { (void)hipSetDevice(plan->device); (void)hipStreamSynchronize(plan->stream); delete plan; } });
+    return guarded([&] {
+        if (!plan) return;
+        if (plan->multi) multi_synchronize(plan);
+        else { (void)hipSetDevice(plan->device); (void)hipStreamSynchronize(plan->stream); }
+        delete plan;
+    });
 }
 
 int64_t lsfc_plan_size(const lsfc_plan* plan) { return plan ? plan->N : -1; }
@@ -486,6 +497,16 @@ const char* lsfc_plan_pipeline(const lsfc_plan* plan) {
 int lsfc_plan_set_nu(lsfc_plan* plan, const double* nu, int memspace) {
     return guarded([&] {
         LSFC_REQUIRE(plan && nu, "NULL argument");
+        if (plan->multi) {
+            LSFC_REQUIRE(memspace == LSFC_MEM_HOST, "a multi-device plan takes nu from the host");
+            int64_t off = 0;
+            for (auto& sp : plan->multi->sub) {
+                LSFC_HIP(hipSetDevice(sp->device));
+                LSFC_HIP(hipMemcpy(sp->nu.p, nu + off, sp->N * sizeof(double), hipMemcpyHostToDevice));
+                off += sp->N;
+            }
+            return;
+        }
         LSFC_HIP(hipSetDevice(plan->device));
         LSFC_HIP(hipMemcpyAsync(plan->nu.p, nu, plan->N * sizeof(double),
                                 memspace == LSFC_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, plan->stream));
@@ -496,6 +517,7 @@ int lsfc_plan_set_nu(lsfc_plan* plan, const double* nu, int memspace) {
 int lsfc_plan_get_symbol(const lsfc_plan* plan, double* out, int64_t capacity_complex, int64_t* count) {
     return guarded([&] {
         LSFC_REQUIRE(plan && count, "NULL argument");
+        LSFC_REQUIRE(!plan->multi, "not available on a multi-device plan");
         *count = (int64_t)plan->sym.n;
         if (out) {
             LSFC_REQUIRE(capacity_complex >= (int64_t)plan->sym.n, "buffer too small");
@@ -522,7 +544,7 @@ int lsfc_apply_batch(lsfc_plan* plan, const double* x, double* y, int64_t nrhs, 
 int lsfc_sample_sources(lsfc_plan* plan, const int64_t* sources, int64_t nsrc, double* out, int memspace) {
     return guarded([&] {
         LSFC_REQUIRE(plan && sources && out && nsrc >= 1, "bad argument");
-        LSFC_REQUIRE(!plan->dist, "not available on a distributed plan");
+        LSFC_REQUIRE(!plan->dist && !plan->multi, "not available on a distributed plan");
         LSFC_HIP(hipSetDevice(plan->device));
         lsfc_plan* p = plan;
         const int64_t N = p->N;
@@ -563,7 +585,10 @@ int lsfc_gmres(lsfc_plan* plan, double* x, const double* b, const lsfc_gmres_opt
         LSFC_REQUIRE(plan && x && b, "NULL argument");
         LSFC_HIP(hipSetDevice(plan->device));
         lsfc_gmres_result local; lsfc_gmres_result* res = result ? result : &local;
-        if (memspace == LSFC_MEM_DEVICE) {
+        if (plan->multi) {
+            LSFC_REQUIRE(memspace == LSFC_MEM_HOST, "a multi-device plan takes host vectors");
+            gmres_run_multi(plan, (cplx*)x, (const cplx*)b, opts, resnorm, resnorm_cap, res);
+        } else if (memspace == LSFC_MEM_DEVICE) {
             gmres_run(plan, (cplx*)x, (const cplx*)b, opts, resnorm, resnorm_cap, res);
         } else {
             LSFC_REQUIRE(memspace == LSFC_MEM_HOST, "unknown memspace %d", memspace);
@@ -580,15 +605,24 @@ int lsfc_gmres(lsfc_plan* plan, double* x, const double* b, const lsfc_gmres_opt
 }
 
 int lsfc_plan_set_stream(lsfc_plan* plan, void* hip_stream) {
-    return guarded([&] { LSFC_REQUIRE(plan, "NULL plan"); plan->stream = (hipStream_t)hip_stream; });
+    return guarded([&] {
+        LSFC_REQUIRE(plan, "NULL plan");
+        LSFC_REQUIRE(!plan->multi, "a multi-device plan runs on the streams of its ranks");
+        plan->stream = (hipStream_t)hip_stream;
+    });
 }
 int lsfc_plan_synchronize(lsfc_plan* plan) {
-    return guarded([&] { LSFC_REQUIRE(plan, "NULL plan"); LSFC_HIP(hipSetDevice(plan->device)); LSFC_HIP(hipStreamSynchronize(plan->stream)); });
+    return guarded([&] {
+        LSFC_REQUIRE(plan, "NULL plan");
+        if (plan->multi) { multi_synchronize(plan); return; }
+        LSFC_HIP(hipSetDevice(plan->device)); LSFC_HIP(hipStreamSynchronize(plan->stream));
+    });
 }
 
 int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value) {
     return guarded([&] {
         LSFC_REQUIRE(plan && key, "NULL argument");
+        if (plan->multi) { for (auto& sp : plan->multi->sub) { const int rc = lsfc_plan_set_tuning(sp.get(), key, value); if (rc != LSFC_OK) fail(rc, "%s", lsfc_last_error()); } return; }
         const std::string k(key);
         if (k == "split_x") plan->tuning.split_x = value != 0;
         else if (k == "split_s") plan->tuning.split_s = value != 0;
@@ -605,6 +639,7 @@ int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value) {
 int lsfc_time_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int reps, double* ms_total) {
     return guarded([&] {
         LSFC_REQUIRE(plan && x_dev && y_dev && ms_total && reps >= 1, "bad argument");
+        LSFC_REQUIRE(!plan->multi, "time a multi-device plan from the host around lsfc_multi_apply_dev + lsfc_plan_synchronize");
         LSFC_HIP(hipSetDevice(plan->device));
         hipEvent_t e0, e1;
         LSFC_HIP(hipEventCreate(&e0)); LSFC_HIP(hipEventCreate(&e1));
@@ -621,7 +656,9 @@ int lsfc_time_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int rep
 int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int reps, int max_stages, const char** names,
                        double* ms, double* bytes, int* nstages) {
     return guarded([&] {
-        LSFC_REQUIRE(plan && x_dev && y_dev && names && ms && bytes && nstages && reps >= 1, "bad argument");
+        LSFC_REQUIRE(plan && names && ms && bytes && nstages && reps >= 1, "bad argument");
+        if (plan->multi) { multi_profile(plan, reps, max_stages, names, ms, bytes, nstages); return; }    // (on the ranks' staging vectors)
+        LSFC_REQUIRE(x_dev && y_dev, "bad argument");
         LSFC_HIP(hipSetDevice(plan->device));
         lsfc_plan* p = plan;
         const cplx* x = (const cplx*)x_dev; cplx* y = (cplx*)y_dev;

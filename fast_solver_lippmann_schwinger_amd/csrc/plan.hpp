@@ -50,6 +50,7 @@ struct DistState {
     bool force_overlap = false, force_comm = false;
     bool no_overlap = false, split_edges = true;     // LSFC_DIST_OVERLAP=0 / LSFC_DIST_SPLIT_EDGES=0, read at plan creation
     bool sim = false;        // simulated ranks in one process (tests): exchanges done by lsfc_dist_sim_apply
+    bool member = false;     // rank of a single-process multi-device plan (MultiState): driven by the parent plan only
     void* comm = nullptr;    // ncclComm_t
     void* comm2 = nullptr;   // second communicator: the way back runs on its own stream, concurrently with the way in
     int lz = 0;              // local z planes (l / nranks)
@@ -62,6 +63,18 @@ struct DistState {
     std::vector<hipEvent_t> ev_in, ev_done, ev_back;
     hipEvent_t ev_p1 = nullptr, ev_p1a = nullptr, ev_backa = nullptr;   // x pass done / its first z half done / first z half of the last chunk back
     ~DistState();
+};
+
+// Single-process multi-device plan (dist.hip): ONE host thread drives P z-slab ranks, one per device -- the form a
+// single-process host (the reference is one Julia process, examples/example3D.jl:54,78) uses to reach the multi-GPU path.
+struct MultiState {
+    int P = 0;
+    std::vector<int> devices;                        // devices[r] of rank r (repeats allowed with the copy transport: tests)
+    std::vector<std::unique_ptr<lsfc_plan>> sub;     // sub[r]: the slab plan of rank r (DistState::member)
+    bool rccl = false;                               // transport of the two slab exchanges: RCCL grouped send/recv, or peer copies
+    std::vector<void*> comm, comm2;                  // ncclComm_t per rank (ncclCommInitAll): way in / way back
+    cplx* red_pin = nullptr;                         // pinned host scratch of the scalar reductions (copy transport)
+    ~MultiState();
 };
 
 } // namespace lsfc
@@ -108,6 +121,7 @@ struct lsfc_plan {
 
     std::unique_ptr<lsfc::GmresWorkspace> gmres;
     std::unique_ptr<lsfc::DistState> dist;
+    std::unique_ptr<lsfc::MultiState> multi;
 
     lsfc_plan();
     ~lsfc_plan();
@@ -150,8 +164,18 @@ void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y,
 void plan_make_twiddles(lsfc_plan* p, int axis, int L);
 void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>& perm_y, const std::vector<int>& perm_z, DevBuf<int>& pyrow);
 
+// single-process multi-device plan (dist.hip): x[r], y[r] = device pointers of rank r's slab on devices[r]
+void multi_convolve_dev(lsfc_plan* root, const cplx* const* x, cplx* const* y, bool use_nu, double alpha, double beta);
+void multi_convolve_host(lsfc_plan* root, const cplx* x, cplx* y, bool use_nu, double alpha, double beta);   // scatter, apply, gather
+void multi_allreduce_sum(lsfc_plan* root, cplx* const* dev, int count);   // dev[r] on devices[r], stream-ordered on the sub-plan streams
+void multi_synchronize(lsfc_plan* root);
+void multi_profile(lsfc_plan* root, int reps, int max_stages, const char** names, double* ms, double* bytes, int* nstages);
+
 // GMRES (gmres.hip)
 void gmres_run(lsfc_plan* p, cplx* x_dev, const cplx* b_dev, const lsfc_gmres_opts* opts, double* resnorm, int64_t cap,
                lsfc_gmres_result* res);
+// multi-device plan: x (in/out) and b are HOST vectors of the full size; the Krylov basis is spread over the devices
+void gmres_run_multi(lsfc_plan* root, cplx* x_host, const cplx* b_host, const lsfc_gmres_opts* opts, double* resnorm, int64_t cap,
+                     lsfc_gmres_result* res);
 
 } // namespace lsfc

@@ -63,6 +63,71 @@ def build_distributed_3d(n, h, k, nu_local, rank, nranks, device, m=None, l=None
     return FastM3D(None, nuv, 4 * n, 4 * m, 4 * l, n, m, l, k, _plan=plan)
 
 
+class MultiDeviceFastM3D(FastM3D):
+    """`buildFastConvolution3D` on several GPUs driven from THIS one process (lsfc_plan_create_gv3d_multi): the form a
+    single-process host -- the reference is one Julia process, examples/example3D.jl:54,78 -- uses to reach the
+    multi-GPU path.  Behaves like FastM3D with host (numpy) vectors: ``M * b``, ``mul_``, ``FFTconvolution``,
+    ``gmres_`` (host preconditioner callback).  ``devices`` may list a device more than once (logical ranks on one GPU,
+    peer-copy transport): that is how the path is tested where only one GPU is visible."""
+
+    def __init__(self, n, h, k, nu, devices, m=None, l=None, flags=0):
+        m = n if m is None else m
+        l = n if l is None else l
+        nuv = np.ascontiguousarray(nu, dtype=np.float64).reshape(-1)
+        if nuv.size != n * m * l:
+            raise ValueError("DimensionMismatch: nu")
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        plan = C.c_void_p()
+        L.check(L.load().lsfc_plan_create_gv3d_multi(C.byref(plan), n, m, l, float(n * h), float(k), nuv.ctypes.data_as(C.c_void_p),
+                                                     flags, devs, len(devices)))
+        super().__init__(None, nuv, 4 * n, 4 * m, 4 * l, n, m, l, k, _plan=plan)
+        self.devices = [int(d) for d in devices]
+
+    def _info(self):
+        nd, ln, tr = C.c_int(0), C.c_int64(0), C.c_char_p()
+        L.check(L.load().lsfc_multi_info(self._plan, C.byref(nd), None, C.byref(ln), C.byref(tr)))
+        return nd.value, ln.value, tr.value.decode()
+
+    @property
+    def transport(self):
+        return self._info()[2]
+
+    @property
+    def local_n(self):
+        return self._info()[1]
+
+    def apply_dev(self, xs, ys, mode=0):
+        """device-resident slabs: xs[r], ys[r] = torch complex128 tensors on cuda:devices[r] (stream-ordered, no copy)"""
+        P = len(self.devices)
+        xp = (C.c_void_p * P)(*[x.data_ptr() for x in xs])
+        yp = (C.c_void_p * P)(*[y.data_ptr() for y in ys])
+        L.check(L.load().lsfc_multi_apply_dev(self._plan, xp, yp, mode))
+
+    def bench(self, steps, warmup):
+        """`steps` timed applies on device-resident slabs (host clock around the enqueue + a synchronisation of every
+        device), and the per-stage profile: what bench.py --single-process reports"""
+        import time
+        import torch
+        from .operators import profile_apply
+        ln = self.local_n
+        xs, ys = [], []
+        for r, d in enumerate(self.devices):
+            g = torch.Generator(device=f"cuda:{d}"); g.manual_seed(20250224 + r)
+            xs.append(torch.randn(ln, dtype=torch.complex128, device=f"cuda:{d}", generator=g))
+            ys.append(torch.empty(ln, dtype=torch.complex128, device=f"cuda:{d}"))
+        for d in set(self.devices):
+            torch.cuda.synchronize(d)
+        for _ in range(warmup):
+            self.apply_dev(xs, ys)
+        self.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.apply_dev(xs, ys)
+        self.synchronize()
+        elapsed = time.perf_counter() - t0
+        return {"elapsed_s": elapsed, "stages": profile_apply(self, None, None, reps=3)}
+
+
 class SimulatedRanks:
     """`nranks` logical ranks on ONE device (lsfc_dist_sim_*): the test double of the multi-GPU operator.  Same
     kernels, layouts and symbol slabs; the two slab exchanges are device-to-device copies instead of RCCL."""

@@ -427,8 +427,10 @@ def time_apply(M, x_dev, y_dev, reps):
 
 
 def profile_apply(M, x_dev, y_dev, reps=3):
-    px, _, _ = _vec(x_dev, M.N, "x")
-    py, _, _ = _vec(y_dev, M.N, "y")
+    """(kernel / stage name, mean ms, algorithmic bytes) of one apply; a multi-device plan profiles on its own staging
+    vectors (pass None, None)"""
+    px = _vec(x_dev, M.N, "x")[0] if x_dev is not None else None
+    py = _vec(y_dev, M.N, "y")[0] if y_dev is not None else None
     names = (C.c_char_p * 16)()
     ms, nb, ns = (C.c_double * 16)(), (C.c_double * 16)(), C.c_int(0)
     L.check(L.load().lsfc_profile_apply(M._plan, px, py, int(reps), 16, names, ms, nb, C.byref(ns)))

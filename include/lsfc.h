@@ -261,6 +261,29 @@ int lsfc_dist_sim_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_
                                    const double* nu_local, unsigned flags, int device, int rank, int nranks);
 int lsfc_dist_sim_apply(lsfc_plan** plans, int nranks, const double* const* x, double* const* y, int mode);
 
+/* ---- single-process multi-device 3D operator (ONE host thread drives every GPU) ---- */
+
+/* buildFastConvolution3D for a host that is ONE process -- the reference's own situation (a single Julia process,
+ * examples/example3D.jl:54,78) -- on `ndev` devices: rank r = devices[r] owns z planes [r*l/ndev, (r+1)*l/ndev).
+ * nu: the full n*m*l contrast (host).  The returned plan behaves like any other with HOST vectors: lsfc_apply,
+ * lsfc_convolve, lsfc_apply_batch, lsfc_gmres (host preconditioner callback on the whole vector), lsfc_plan_set_nu,
+ * lsfc_profile_apply (x_dev / y_dev ignored), lsfc_plan_synchronize, lsfc_plan_destroy; vectors are scattered over the
+ * devices' slabs inside the call and the Krylov basis of lsfc_gmres stays distributed on the devices.  The calling
+ * thread enqueues the work of all ranks: x pass -> slab exchange -> y, z, y passes -> slab exchange back -> x pass,
+ * in K pipeline chunks with the exchanges on side streams, cross-device ordering by events.
+ * Transport of the two exchanges: RCCL grouped ncclSend/ncclRecv over ncclCommInitAll communicators (default when the
+ * devices are distinct), or peer-to-peer copies issued by the source rank (environment LSFC_MULTI_TRANSPORT=copy; the
+ * only choice when a device is listed more than once, which is how this path is tested on a one-GPU machine).
+ * ndev: a power of two dividing l and Lx/8. */
+int lsfc_plan_create_gv3d_multi(lsfc_plan** out, int64_t n, int64_t m, int64_t l, double box, double omega,
+                                const double* nu, unsigned flags, const int* devices, int ndev);
+/* ndev, devices[0..ndev), entries per device slab, name of the exchange transport (any pointer may be NULL) */
+int lsfc_multi_info(const lsfc_plan* plan, int* ndev, int* devices, int64_t* local_n, const char** transport);
+/* The apply on vectors that already live on the devices: x_dev[r], y_dev[r] = slab of rank r in the memory of
+ * devices[r].  Stream-ordered on every device (lsfc_plan_synchronize waits for all of them).  mode: 0 apply,
+ * 1 convolve, 2 convolve with nu. */
+int lsfc_multi_apply_dev(lsfc_plan* plan, const double* const* x_dev, double* const* y_dev, int mode);
+
 /* Padded line length the hand-written pipeline uses for an axis of n grid points: the smallest of 2^k, 3*2^k, 5*2^k
  * (32 ... 2048) that is >= 2n; 0 if there is none (such axes run through rocFFT on the exact 2n grid).  Pure host
  * arithmetic, no device needed.  (The reference pads every axis to 4n, src/FastConvolution3D.jl:48.) */

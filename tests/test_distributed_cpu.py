@@ -106,3 +106,43 @@ def test_slab_range():
     assert slab_range(512, 3, 8) == (192, 256)
     with pytest.raises(ValueError):
         slab_range(10, 0, 4)
+
+
+def test_bench_self_launch_command_and_relay(tmp_path):
+    # `python bench.py --gpus N` started directly must launch N ranks itself, BEFORE touching a GPU, and relay rank 0's
+    # line: the launcher path is exercised here with a stand-in rank script (gloo, CPU) through the same code
+    import subprocess
+    import sys
+    import bench as B
+    cmd = B.launcher_command(["--gpus", "2", "--steps", "3"], 2)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    # relay: a fake two-rank job that prints one JSON line from rank 0 and noise from rank 1
+    script = tmp_path / "fake_rank.py"
+    script.write_text(
+        "import os, json, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "r = dist.get_rank()\n"
+        "print('noise from rank', r, flush=True)\n"
+        "if r == 0: print(json.dumps({'metric': 'm', 'value': 1.0, 'n_gpus': dist.get_world_size()}), flush=True)\n"
+        "dist.destroy_process_group()\n")
+    out = subprocess.run([sys.executable, "-c",
+                          "import sys; sys.path.insert(0, %r); import bench as B\n"
+                          "B.launcher_command = lambda argv, n: %r\n"
+                          "B.self_launch([], 2)" % (os.path.dirname(os.path.abspath(B.__file__)),
+                                                    cmd[:cmd.index(os.path.abspath(B.__file__))] + [str(script)])],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and '"n_gpus": 2' in lines[0]              # ONE line on stdout; the noise went to stderr
+    assert "noise from rank" in out.stderr
+    # a failing child must give a non-zero exit code and no line
+    bad = tmp_path / "bad_rank.py"
+    bad.write_text("raise SystemExit(3)\n")
+    out = subprocess.run([sys.executable, "-c",
+                          "import sys; sys.path.insert(0, %r); import bench as B\n"
+                          "B.launcher_command = lambda argv, n: %r\n"
+                          "B.self_launch([], 2)" % (os.path.dirname(os.path.abspath(B.__file__)),
+                                                    cmd[:cmd.index(os.path.abspath(B.__file__))] + [str(bad)])],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not out.stdout.strip()

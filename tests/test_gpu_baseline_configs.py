@@ -162,10 +162,10 @@ def test_config4_n256_omega64pi_patched_and_host_callback(lsfc, n256):
     u_inc = _plane_wave_x(k, x, n)
     rhs = -(M * u_inc - u_inc)
     u = np.zeros(n ** 3, complex)
-    u, hist = lsfc.gmres_(u, M, rhs, Pl=Pl, restart=30, reltol=1e-6, maxiter=60, log=True)
+    u, hist = lsfc.gmres_(u, M, rhs, Pl=Pl, restart=30, reltol=1e-6, maxiter=24, log=True)
     assert len(calls) == hist.mvps + 1
     uo = np.zeros(n ** 3, complex)
-    uo, ho = o.gmres(uo, A, rhs, Pl=lambda v: v / d, restart=30, reltol=1e-6, maxiter=60)
+    uo, ho = o.gmres(uo, A, rhs, Pl=lambda v: v / d, restart=30, reltol=1e-6, maxiter=24)
     assert hist.isconverged == ho.isconverged
     _check_history(hist, ho, 1e-6)
     assert rel_err(u, uo) < 1e-5
@@ -199,6 +199,7 @@ def test_n512_full_size_apply_vs_oracle(lsfc, label):
     print(f"[n512 {label}] oracle symbol {A.seconds:.0f} s, oracle apply {time.time() - t0:.0f} s")
     del A
     err = rel_err(y, ref)
+    print(f"[n512 {label}] relative l2 vs oracle {err:.3e}")
     assert err < TOL, err
 
 

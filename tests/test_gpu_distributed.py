@@ -106,3 +106,101 @@ def test_simulated_ranks_grid_sizes_not_powers_of_two(lsfc, shape, ranks):
         S = SimulatedRanks(n, m, l, h, k, nu, nranks)
         assert rel_err(S.apply(b), ref) < 1e-13
         S.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# single-process multi-device plan (lsfc_plan_create_gv3d_multi): the host is ONE process, as the reference's
+# (examples/example3D.jl:54,78).  On a one-GPU box the device is listed P times: P logical ranks with their own
+# streams, events and buffers, slab exchanges by source-issued device copies -- the same enqueue order, event graph
+# and kernels as with P GPUs.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ndev,overlap", [(1, "1"), (2, "1"), (4, "1"), (4, "0"), (8, "1")])
+def test_multi_device_plan_matches_oracle(lsfc, monkeypatch, ndev, overlap):
+    from fast_solver_lippmann_schwinger_amd.distributed import MultiDeviceFastM3D
+    monkeypatch.setenv("LSFC_DIST_OVERLAP", overlap)
+    c = cases.case_3d("gv32k10")
+    Mo, b, n = c["M"], c["b"], c["n"]
+    M = MultiDeviceFastM3D(n, c["h"], c["k"], Mo.nu, devices=[0] * ndev)
+    assert M.N == n ** 3 and M.local_n == n ** 3 // ndev and M.pipeline == "pruned-hip"
+    assert ("copies" in M.transport) == (ndev > 1)
+    ref = o.mul(Mo, b)
+    for _ in range(3):                                    # repeated applies re-use the exchange buffers and events
+        assert rel_err(M * b, ref) < TOL
+    assert rel_err(lsfc.FFTconvolution(M, b), o.fft_convolution(Mo, b)) < TOL
+    y = np.empty_like(b)
+    M.mul_(y, b)
+    assert rel_err(y, ref) < TOL
+    st = dict((s, ms) for s, ms, _ in lsfc.profile_apply(M, None, None, reps=1))
+    assert set(st) == {"xfwd", "alltoall_in", "yfwd", "zfused", "yinv", "alltoall_back", "xinv"}
+    M.close()
+
+
+def test_multi_device_plan_device_resident_slabs_and_split_edges(lsfc, monkeypatch):
+    import torch
+    from fast_solver_lippmann_schwinger_amd.distributed import MultiDeviceFastM3D
+    n, m, l, k, P = 64, 16, 32, 9.0, 4
+    h = 1.0 / n
+    rng = np.random.default_rng(11)
+    nu = rng.uniform(-0.3, 0.3, n * m * l)
+    b = o.random_vector(n * m * l)
+    x = -0.5 + h * np.arange(n)
+    M1 = lsfc.buildFastConvolution3D(x, x[:m], x[:l], None, None, None, h, k, nu)
+    ref = M1 * b
+    for edges in ("1", "0"):
+        monkeypatch.setenv("LSFC_DIST_SPLIT_EDGES", edges)
+        M = MultiDeviceFastM3D(n, h, k, nu, devices=[0] * P, m=m, l=l)
+        ln = M.local_n
+        xs = [torch.from_numpy(b[r * ln:(r + 1) * ln]).cuda() for r in range(P)]
+        ys = [torch.empty_like(v) for v in xs]
+        for _ in range(4):
+            M.apply_dev(xs, ys)
+        M.synchronize()
+        got = np.concatenate([v.cpu().numpy() for v in ys])
+        assert rel_err(got, ref) < 1e-13, edges
+        M.apply_dev(xs, xs)                               # y may alias x, slab by slab
+        M.synchronize()
+        assert rel_err(np.concatenate([v.cpu().numpy() for v in xs]), ref) < 1e-13
+        M.close()
+
+
+@pytest.mark.parametrize("orth", ["ModifiedGramSchmidt", "ClassicalGramSchmidt", "DGKS"])
+def test_multi_device_gmres_matches_single_gpu_and_oracle(lsfc, orth):
+    # the Krylov basis spread over 4 ranks, inner products completed across them; host preconditioner on the whole vector
+    from fast_solver_lippmann_schwinger_amd.distributed import MultiDeviceFastM3D
+    c = cases.case_3d("gv16k10")
+    Mo, n = c["M"], c["n"]
+    M = MultiDeviceFastM3D(n, c["h"], c["k"], Mo.nu, devices=[0, 0, 0, 0])
+    M1 = lsfc.FastM3D(Mo.GFFT, Mo.nu, Mo.ne, Mo.me, Mo.le, n, n, n, Mo.omega)
+    u_inc = cases.plane_wave(c["k"], c["X"])
+    rhs = -(M * u_inc - u_inc)
+    d = 1.0 + Mo.omega ** 2 * 0.01 * Mo.nu
+    calls = []
+
+    def Pl(v):
+        assert v.size == n ** 3                            # the WHOLE vector, as ldiv!(Pl, v) sees it
+        calls.append(1)
+        v /= d
+
+    for pl in (None, Pl):
+        u = np.zeros(M.N, complex)
+        u, hist = lsfc.gmres_(u, M, rhs, Pl=pl, restart=5, reltol=1e-10, log=True, orth_meth=orth)
+        u1 = np.zeros(M.N, complex)
+        u1, h1 = lsfc.gmres_(u1, M1, rhs, Pl=pl, restart=5, reltol=1e-10, log=True, orth_meth=orth)
+        assert hist.isconverged and hist.iters == h1.iters and hist.mvps == h1.mvps
+        assert np.max(np.abs(hist["resnorm"] - h1["resnorm"]) / h1["resnorm"]) < 1e-6
+        assert rel_err(u, u1) < 1e-9
+        G2 = o.reduce_symbol(Mo.GFFT, (n, n, n))
+        A = lambda v: o.apply_reduced(G2, Mo.nu, Mo.omega, v, (n, n, n))
+        if pl is None:
+            assert np.linalg.norm(A(u) - rhs) / np.linalg.norm(rhs) < 2e-10
+    assert len(calls) > 0
+    M.close()
+
+
+def test_multi_device_plan_argument_errors(lsfc):
+    from fast_solver_lippmann_schwinger_amd.distributed import MultiDeviceFastM3D
+    nu = np.zeros(32 ** 3)
+    with pytest.raises(lsfc.LsfcError):
+        MultiDeviceFastM3D(32, 1 / 32, 5.0, nu, devices=[0, 0, 0])          # 3 ranks: not a power of two dividing l
+    with pytest.raises(lsfc.LsfcError):
+        MultiDeviceFastM3D(32, 1 / 32, 5.0, nu, devices=[0, 99])            # no such device
