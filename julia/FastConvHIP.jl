@@ -55,6 +55,17 @@ function buildFastConvolution3D(x, y, z, X, Y, Z, h, k, nu; quadRule::String="Gr
     FastMHIP(plan[], nuv, length(x), length(y), length(z), k, quadRule)
 end
 
+# The same builder on several GPUs, driven from THIS one Julia process (lsfc_plan_create_gv3d_multi): z-slabs over
+# `devices` (0-based HIP device ids), RCCL exchanges over xGMI inside the library.  The returned object is an ordinary
+# FastMHIP: `*`, `mul!`, `FFTconvolution`, `gmres_hip!` take and return full host vectors.
+function buildFastConvolution3D(x, y, z, X, Y, Z, h, k, nu, devices::Vector{<:Integer}; quadRule::String="Greengard_Vico", flags=0)
+    nuv = Vector{Float64}(nu(X, Y, Z)); plan = Ref{Ptr{Cvoid}}(C_NULL); devs = Cint.(devices)
+    check(ccall((:lsfc_plan_create_gv3d_multi, liblsfc), Cint,
+                (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Float64, Float64, Ptr{Float64}, Cuint, Ptr{Cint}, Cint),
+                plan, length(x), length(y), length(z), abs(x[end] - x[1]) + h, k, nuv, flags, devs, length(devs)))
+    FastMHIP(plan[], nuv, length(x), length(y), length(z), k, quadRule)
+end
+
 # buildFastConvolution(x,y,h,k,nu; quadRule) -- src/FastConvolution.jl:170
 function buildFastConvolution(x, y, h, k, nu::Function; quadRule::String="trapezoidal", flags=0, device=0)
     n, m = length(x), length(y)
