@@ -55,6 +55,7 @@ SIGNATURES = {
     "lsfc_apply_batch": (_I, [_P, _P, _P, _L, _I, _I]),
     "lsfc_sample_sources": (_I, [_P, _P, _L, _P, _I]),
     "lsfc_gmres": (_I, [_P, _P, _P, C.POINTER(GmresOpts), _P, _L, C.POINTER(GmresResult), _I]),
+    "lsfc_gmres_batch": (_I, [_P, _P, _P, _L, C.POINTER(GmresOpts), _P, _L, C.POINTER(GmresResult), _I]),
     "lsfc_precond_create": (_I, [_PP, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I]),
     "lsfc_precond_destroy": (_I, [_P]),
     "lsfc_precond_set_stream": (_I, [_P, _P]),

@@ -41,8 +41,11 @@ static constexpr int XB = 8;           // x' lines per strided workgroup: 8 * 16
 // EXACT: n == L/2 (the grid fills the line): the end-of-line predicates compile away
 template <class C, int LPW, bool SPLIT, bool EXACT>
 __global__ __launch_bounds__(C::T * LPW)
-void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __restrict__ out,
+void k_xfwd(const VecBatch vb, int64_t obatch, const double* __restrict__ nu, cplx* __restrict__ out,
             const cplx* __restrict__ tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride) {
+    // blockIdx.y = right-hand side of the batch
+    const cplx* __restrict__ x = vb.x[blockIdx.y];
+    out += (int64_t)blockIdx.y * obatch;
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -77,8 +80,11 @@ void k_xfwd(const cplx* __restrict__ x, const double* __restrict__ nu, cplx* __r
 
 template <class C, int LPW, bool SPLIT, bool EXACT>
 __global__ __launch_bounds__(C::T * LPW)
-void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alpha, double beta,
+void k_xinv(const cplx* __restrict__ in, const VecBatch vb, int64_t ibatch, double alpha, double beta,
             const cplx* __restrict__ tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride) {
+    const cplx* xorig = vb.x[blockIdx.y];
+    cplx* y = vb.y[blockIdx.y];
+    in += (int64_t)blockIdx.y * ibatch;
     using LL = LdsLayout<1, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -110,8 +116,10 @@ void k_xinv(const cplx* __restrict__ in, const cplx* xorig, cplx* y, double alph
 // A1[Lx][m][l] (natural) -> A2[XB][l][Ly][Lx/XB]
 template <class C, int LINES, bool SPLIT, int WPE, bool EXACT>
 __global__ __launch_bounds__(C::T * LINES, WPE)
-void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ, int p1, int p2) {
+void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ, int p1, int p2,
+            int64_t batch1, int64_t batch2) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
+    a1 += (int64_t)blockIdx.y * batch1; a2 += (int64_t)blockIdx.y * batch2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, Ly = C::L;
     const int xi = threadIdx.x % LINES, t = threadIdx.x / LINES;
@@ -137,8 +145,10 @@ void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __re
 
 template <class C, int LINES, bool SPLIT, int WPE, bool EXACT>
 __global__ __launch_bounds__(C::T * LINES, WPE)
-void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ, int p1, int p2) {
+void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __restrict__ tw, int Lx, int m, int l, int TG, int TZ, int p1, int p2,
+            int64_t batch1, int64_t batch2) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
+    a1 += (int64_t)blockIdx.y * batch1; a2 += (int64_t)blockIdx.y * batch2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, Ly = C::L;
     const int xi = threadIdx.x % LINES, t = threadIdx.x / LINES;
@@ -179,11 +189,14 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
 // fetched through LDS (zm[s - L/2] = storage index of the partner).  Halves the symbol bytes of the pass again.
 // TWL: the full stage-twiddle table (tw points to it) is staged in LDS behind the exchange buffer and read instead of
 // computing the power trees (-18 % fp64 instructions, +40 % LDS reads).
-template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF, bool ZE, bool EXACT, bool TWL>
+// MULTI (several right-hand sides, lsfc_apply_batch): the workgroup runs the tile of every batch member in turn with
+// ONE load of its symbol tile -- the symbol's share of the pass (8 of 16 complex per point in the byte model, 4 with
+// the half symbol) is paid once per batch instead of once per right-hand side.
+template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF, bool ZE, bool EXACT, bool TWL, bool MULTI = false>
 __global__ __launch_bounds__(C::T * LINES, WPE)
 void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
               int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
-              const int2* __restrict__ ytab, const int* __restrict__ zm, int nin) {
+              const int2* __restrict__ ytab, const int* __restrict__ zm, int nin, int nrhs, int64_t dBatch) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -209,6 +222,49 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
         tw = tl;
     }
     cplx v[E];
+    if constexpr (MULTI) {
+        // symbol tile once, then every right-hand side of the batch
+        constexpr int H = ZE ? E / 2 : E;
+        cplx sv[H];
+#pragma unroll
+        for (int e = 0; e < H; ++e) sv[e] = s[sLine * (t + T * e)];
+        int part[ZE ? H : 1];
+        cplx smid = make_double2(0.0, 0.0);
+        if constexpr (ZE) {
+#pragma unroll
+            for (int e = 0; e < H; ++e) part[e] = zm[t + T * e];
+            if (t == 0) smid = s[sLine * (C::L / 2)];
+        }
+        for (int r = 0; r < nrhs; ++r) {
+            cplx* dr = d + (int64_t)r * dBatch;
+#pragma unroll
+            for (int e = 0; e < E / 2; ++e) v[e] = (EXACT || t + T * e < nin) ? dr[dLine * (t + T * e)] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
+            fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+            if constexpr (ZE) {
+                cplx* stage = reinterpret_cast<cplx*>(smem);
+#pragma unroll
+                for (int e = 0; e < H; ++e) stage[(t + T * e) * LINES + li] = sv[e];
+                if (t == 0) stage[(C::L / 2) * LINES + li] = smid;
+                LSFC_BARRIER();
+#pragma unroll
+                for (int e = 0; e < H; ++e) {
+                    v[e] = cmul(v[e], sv[e]);
+                    v[e + H] = cmul(v[e + H], stage[part[e] * LINES + li]);
+                }
+                LSFC_BARRIER();
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = cmul(v[e], sv[e]);
+            }
+            fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+#pragma unroll
+            for (int e = 0; e < E / 2; ++e) if (EXACT || t + T * e < nin) dr[dLine * (t + T * e)] = v[e];
+            // (every exchange ends with a barrier after its reads: the buffer is free for the next member)
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) v[e] = (EXACT || t + T * e < nin) ? d[dLine * (t + T * e)] : make_double2(0.0, 0.0);
 #pragma unroll
@@ -281,21 +337,21 @@ template <class C> struct Tune {
     static constexpr int LINES = (C::T * XB <= 512 || (C::E <= 8 && C::T * XB <= 1024)) ? XB : 512 / C::T;
 };
 
-template <class C, bool SPLIT> static void xfwd_t(const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride, hipStream_t st) {
+template <class C, bool SPLIT> static void xfwd_t(const VecBatch& vb, int nrhs, int64_t obatch, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = (n == C::L / 2) ? k_xfwd<C, LPW, SPLIT, true> : k_xfwd<C, LPW, SPLIT, false>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, x, nu, out, tw, nlines, wmagic, W, Wp, n, bstride);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW), (unsigned)nrhs), dim3(C::T * LPW), lds, st, vb, obatch, nu, out, tw, nlines, wmagic, W, Wp, n, bstride);
 }
-template <class C, bool SPLIT> static void xinv_t(const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride, hipStream_t st) {
+template <class C, bool SPLIT> static void xinv_t(const cplx* in, const VecBatch& vb, int nrhs, int64_t ibatch, double alpha, double beta, const cplx* tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride, hipStream_t st) {
     constexpr int LPW = Tune<C>::LPW;
     using LL = LdsLayout<1, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LPW * LL::elem_bytes();
     auto k = (n == C::L / 2) ? k_xinv<C, LPW, SPLIT, true> : k_xinv<C, LPW, SPLIT, false>;
     allow_lds(k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW)), dim3(C::T * LPW), lds, st, in, xo, y, alpha, beta, tw, nlines, wmagic, W, Wp, n, bstride);
+    hipLaunchKernelGGL(k, dim3((unsigned)((nlines + LPW - 1) / LPW), (unsigned)nrhs), dim3(C::T * LPW), lds, st, in, vb, ibatch, alpha, beta, tw, nlines, wmagic, W, Wp, n, bstride);
 }
 static void ytile(const PrunedTuning& tn, int L, int ngrp, int l, int& TG, int& TZ) {
     // auto (0): all groups x 1 plane, except at L >= 1024 where 32 groups x 8 planes keeps the 128-B chunks that the
@@ -304,27 +360,27 @@ static void ytile(const PrunedTuning& tn, int L, int ngrp, int l, int& TG, int& 
     TG = tn.ytile_g > 0 ? tn.ytile_g : ag; if (TG > ngrp) TG = ngrp; while (ngrp % TG) --TG;
     TZ = tn.ytile_z > 0 ? tn.ytile_z : az; if (TZ > l) TZ = l;       while (l % TZ) --TZ;
 }
-template <class C, bool SPLIT, int WPE> static void yfwd_t(const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
+template <class C, bool SPLIT, int WPE> static void yfwd_t(const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st, int nrhs, int64_t b1, int64_t b2) {
     constexpr int LINES = Tune<C>::LINES;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     auto k = (m == C::L / 2) ? k_yfwd<C, LINES, SPLIT, WPE, true> : k_yfwd<C, LINES, SPLIT, WPE, false>;
     allow_lds(k, lds);
     int TG, TZ; ytile(tn, C::L, Lx / LINES, l, TG, TZ);
-    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a1, a2, tw, Lx, m, l, TG, TZ, p1, p2);
+    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l), (unsigned)nrhs), dim3(C::T * LINES), lds, st, a1, a2, tw, Lx, m, l, TG, TZ, p1, p2, b1, b2);
 }
-template <class C, bool SPLIT, int WPE> static void yinv_t(const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
+template <class C, bool SPLIT, int WPE> static void yinv_t(const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st, int nrhs, int64_t b1, int64_t b2) {
     constexpr int LINES = Tune<C>::LINES;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     auto k = (m == C::L / 2) ? k_yinv<C, LINES, SPLIT, WPE, true> : k_yinv<C, LINES, SPLIT, WPE, false>;
     allow_lds(k, lds);
     int TG, TZ; ytile(tn, C::L, Lx / LINES, l, TG, TZ);
-    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l)), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l, TG, TZ, p1, p2);
+    hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l), (unsigned)nrhs), dim3(C::T * LINES), lds, st, a2, a1, tw, Lx, m, l, TG, TZ, p1, p2, b1, b2);
 }
 template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static void zfused_t(cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                                                     int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                                                    const int2* ytab, const int* zm, int nin, hipStream_t st) {
+                                                    const int2* ytab, const int* zm, int nin, hipStream_t st, int nrhs, int64_t dBatch) {
     // dTile/sTile are strides per XB-tile of x'; a workgroup covers LINES of the XB lines of a tile.
     // twl != NULL: full stage-twiddle table, staged in LDS by the kernel.
     constexpr int LINES = Tune<C>::LINES;
@@ -338,16 +394,22 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
         lds += (size_t)C::TWLEN * sizeof(cplx);
         tw = twl;
     }
+    if (nrhs > 1) {
+        // batch: one symbol load per tile for all right-hand sides (the symbol is always loaded up front there, so the
+        // PREFETCH flavours share one instantiation)
+        if (twl) k = (nin == C::L / 2) ? k_zfused<C, LINES, SPLIT, false, WPE, false, ZE, true, true, true> : k_zfused<C, LINES, SPLIT, false, WPE, false, ZE, false, true, true>;
+        else     k = (nin == C::L / 2) ? k_zfused<C, LINES, SPLIT, false, WPE, false, ZE, true, false, true> : k_zfused<C, LINES, SPLIT, false, WPE, false, ZE, false, false, true>;
+    }
     allow_lds(k, lds);
     if (LINES == XB) {
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / XB) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin);
+                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, nrhs, dBatch);
     } else {
         // split each tile into XB/LINES sub-groups: sub-group h starts at xi offset h*LINES
         // (tile, sub-group) collapse to one group index only when tiles are XB-contiguous in xi (2D natural layout)
         LSFC_REQUIRE(dTile == XB && sTile == XB, "sub-tile groups need the natural (2D) layout");
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab, zm, nin);
+                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab, zm, nin, nrhs, dBatch);
     }
 }
 
@@ -363,7 +425,7 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     const int64_t ntiles = (int64_t)(Lx / XB) * nouter;
     LSFC_REQUIRE(ntiles % 8 == 0, "half-tile z pass needs a multiple of 8 tiles");
     hipLaunchKernelGGL(k, dim3((unsigned)(2 * ntiles)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin);
+                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, 1, (int64_t)0);
 }
 
 #if LSFC_FAMILY == 2
@@ -408,32 +470,32 @@ static int chunk_magic(int L, int W) {
     LSFC_REQUIRE(W >= 8 && W <= L && L % W == 0 && L <= 2048, "chunk width %d does not divide the line length %d", W, L);
     return (1 << 22) / W + 1;
 }
-void FAM(pruned_xfwd)(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
+void FAM(pruned_xfwd)(int L, const PrunedTuning& tn, const VecBatch& vb, int nrhs, int64_t obatch, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
     const int wmagic = chunk_magic(L, W);
     if (bstride <= 0) bstride = (int64_t)Wp * nlines;       // dense chunks: [chunk][line][Wp]
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(x, nu, out, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
-    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(x, nu, out, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xfwd_t<C, true>(vb, nrhs, obatch, nu, out, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
+    else            { LSFC_DISPATCH_L(L, (xfwd_t<C, false>(vb, nrhs, obatch, nu, out, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void FAM(pruned_xinv)(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
+void FAM(pruned_xinv)(int L, const PrunedTuning& tn, const cplx* in, const VecBatch& vb, int nrhs, int64_t ibatch, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
     const int wmagic = chunk_magic(L, W);
     if (bstride <= 0) bstride = (int64_t)Wp * nlines;       // dense chunks: [chunk][line][Wp]
-    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, xo, y, alpha, beta, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
-    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, xo, y, alpha, beta, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
+    if (tn.split_x) { LSFC_DISPATCH_L(L, (xinv_t<C, true>(in, vb, nrhs, ibatch, alpha, beta, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
+    else            { LSFC_DISPATCH_L(L, (xinv_t<C, false>(in, vb, nrhs, ibatch, alpha, beta, tw, nlines, wmagic, W, Wp, n, bstride, st))); }
     LSFC_HIP(hipGetLastError());
 }
-void FAM(pruned_yfwd)(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
+void FAM(pruned_yfwd)(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st, int nrhs, int64_t b1, int64_t b2) {
     size_t full_lds = 0;
     LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::LINES, 3, false>::line_elems(C::L) * Tune<C>::LINES * 16));
-    if (tn.split_s || full_lds > (size_t)160 * 1024) { LSFC_DISPATCH_L(L, (yfwd_t<C, true, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
-    else            { LSFC_DISPATCH_L(L, (yfwd_t<C, false, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st))); }
+    if (tn.split_s || full_lds > (size_t)160 * 1024) { LSFC_DISPATCH_L(L, (yfwd_t<C, true, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st, nrhs, b1, b2))); }
+    else            { LSFC_DISPATCH_L(L, (yfwd_t<C, false, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st, nrhs, b1, b2))); }
     LSFC_HIP(hipGetLastError());
 }
-void FAM(pruned_yinv)(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
+void FAM(pruned_yinv)(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st, int nrhs, int64_t b1, int64_t b2) {
     size_t full_lds = 0;
     LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::LINES, 3, false>::line_elems(C::L) * Tune<C>::LINES * 16));
-    if (tn.split_s || full_lds > (size_t)160 * 1024) { LSFC_DISPATCH_L(L, (yinv_t<C, true, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
-    else            { LSFC_DISPATCH_L(L, (yinv_t<C, false, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st))); }
+    if (tn.split_s || full_lds > (size_t)160 * 1024) { LSFC_DISPATCH_L(L, (yinv_t<C, true, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st, nrhs, b1, b2))); }
+    else            { LSFC_DISPATCH_L(L, (yinv_t<C, false, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st, nrhs, b1, b2))); }
     LSFC_HIP(hipGetLastError());
 }
 int FAM(pruned_twfull_len)(int L) {
@@ -447,9 +509,18 @@ void FAM(pruned_twfull)(int L, const cplx* tw, cplx* out) {
 
 void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, const int2* ytab,
-                   const int* zm, int nin, hipStream_t st) {
-#define LSFC_ZF(SP, PF) do { if (zm) { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); } \
-                             else    { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, false>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); } } while (0)
+                   const int* zm, int nin, hipStream_t st, int nrhs, int64_t dBatch) {
+    // the half-tile forms (below) take one right-hand side per launch: a batch runs through them member by member
+    const bool tiled = dLine == 8 && ((int64_t)(Lx / XB) * nouter) % 8 == 0;
+    const bool half_form = (LSFC_FAMILY == 2 && ((L == 1024 && (tn.z_half >= 0 ? tn.z_half : (zm ? 0 : 2)) > 0 && tiled) || (L == 2048 && dLine == 8)))
+                        || (LSFC_FAMILY == 3 && L == 1536 && (tn.z_half >= 0 ? tn.z_half : 1) > 0 && tiled);
+    if (nrhs > 1 && half_form) {
+        for (int r = 0; r < nrhs; ++r)
+            FAM(pruned_zfused)(L, tn, data + (int64_t)r * dBatch, sym, tw, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, 1, 0);
+        return;
+    }
+#define LSFC_ZF(SP, PF) do { if (zm) { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, nrhs, dBatch))); } \
+                             else    { LSFC_DISPATCH_L(L, (zfused_t<C, SP, PF, 1, false>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, nrhs, dBatch))); } } while (0)
     // auto (-1): half-tile, split exchanges, symbol prefetch -- 6.95 -> 6.6 ms at 512^3 (profiles/r01_experiment_half_tile.log)
     // with the z-even half symbol the full-tile form wins (6.05 ms, profiles/r01_experiment_even_z.log)
 #if LSFC_FAMILY == 2

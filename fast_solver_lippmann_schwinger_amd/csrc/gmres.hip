@@ -8,7 +8,11 @@
 #include "pointwise.hpp"
 #include <cmath>
 #include <complex>
+#include <condition_variable>
+#include <exception>
 #include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace lsfc {
@@ -83,17 +87,56 @@ static void solve_least_squares(const std::vector<zc>& H, int ldh, double beta, 
 namespace {
 struct Member { lsfc_plan* p; GmresWorkspace* w; cplx* x; const cplx* b; };
 
+// lsfc_gmres_batch: every right-hand side runs the ordinary solver on its own host thread; the threads meet here
+// whenever they need the operator, and the last one to arrive applies it to all of them in ONE batched pass of the
+// pipeline (plan_convolve_batch_dev).  A solve that has converged leaves the group.
+struct ApplyBatcher {
+    lsfc_plan* p; int active;
+    std::mutex mu, cb_mu;                // cb_mu serialises the user's preconditioner callback
+    std::condition_variable cv;
+    int waiting = 0; uint64_t gen = 0;
+    std::vector<const cplx*> in; std::vector<cplx*> out;
+    std::exception_ptr err;
+    void run_locked() {
+        try {
+            LSFC_HIP(hipSetDevice(p->device));
+            for (size_t j0 = 0; j0 < in.size(); j0 += LSFC_MAX_BATCH) {
+                const int cnt = (int)std::min<size_t>(LSFC_MAX_BATCH, in.size() - j0);
+                VecBatch vb{};
+                for (int j = 0; j < cnt; ++j) { vb.x[j] = in[j0 + j]; vb.y[j] = out[j0 + j]; }
+                plan_convolve_batch_dev(p, cnt, vb, true, 1.0, p->omega * p->omega);
+            }
+        } catch (...) { err = std::current_exception(); }
+        in.clear(); out.clear(); waiting = 0; ++gen;
+        cv.notify_all();
+    }
+    void apply(const cplx* x, cplx* y) {
+        std::unique_lock<std::mutex> lk(mu);
+        in.push_back(x); out.push_back(y); ++waiting;
+        if (waiting == active) run_locked();
+        else { const uint64_t g = gen; cv.wait(lk, [&] { return gen != g; }); }
+        if (err) std::rethrow_exception(err);
+    }
+    void leave() {
+        std::unique_lock<std::mutex> lk(mu);
+        --active;
+        if (active > 0 && waiting == active) run_locked();
+    }
+};
+
 struct Team {
     lsfc_plan* root;
     std::vector<Member> mem;
     bool reduce = false;                // local inner products are partial sums
     GmresWorkspace* rootw = nullptr;    // pinned host vector of the preconditioner callback
+    ApplyBatcher* batcher = nullptr;    // lsfc_gmres_batch: operator applications go through the rendezvous
 
     static void dev(const Member& m) { LSFC_HIP(hipSetDevice(m.p->device)); }
     static cplx* V(const Member& m, int j) { return m.w->V.p + (size_t)j * (size_t)m.p->N; }
     template <class F> void each(F&& f) { for (auto& m : mem) { dev(m); f(m); } }
 
     void apply(const std::function<const cplx*(const Member&)>& in, const std::function<cplx*(const Member&)>& out) {
+        if (batcher) { batcher->apply(in(mem[0]), out(mem[0])); return; }
         if (!root->multi) { dev(mem[0]); plan_apply_dev(root, in(mem[0]), out(mem[0])); return; }
         std::vector<const cplx*> xi; std::vector<cplx*> yo;
         for (auto& m : mem) { xi.push_back(in(m)); yo.push_back(out(m)); }
@@ -128,6 +171,8 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
 
     auto precondition = [&](int col) {
         if (!o.precond) return;
+        std::unique_lock<std::mutex> cb_lock;
+        if (T.batcher) cb_lock = std::unique_lock<std::mutex>(T.batcher->cb_mu);
         if (o.precond_on_device) {
             LSFC_REQUIRE(T.mem.size() == 1, "a device-resident preconditioner callback needs a single-device plan");
             const int rc = o.precond(o.precond_user, (double*)Team::V(T.mem[0], col), T.mem[0].p->N);
@@ -300,6 +345,41 @@ void gmres_run(lsfc_plan* p, cplx* x, const cplx* b, const lsfc_gmres_opts* opts
     // slab-distributed plan (one process per GPU): every inner product / squared norm is completed by an all-reduce over the ranks
     T.reduce = p->dist && !p->dist->sim && !p->dist->member && (p->dist->nranks > 1 || p->dist->force_comm);
     solve(T, opts_in, resnorm, cap, res, r.restart, r.maxiter, r.reltol, r.abstol, r.o);
+}
+
+void gmres_run_batch(lsfc_plan* p, cplx* x, const cplx* b, int nrhs, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap,
+                     lsfc_gmres_result* res) {
+    const Resolved r = resolve(opts_in, p->N);
+    const bool need_vpin = r.o.precond != nullptr && !r.o.precond_on_device;
+    // one workspace (Krylov basis, scalars, pinned buffers) per right-hand side
+    if ((int)p->gmres_batch.size() < nrhs) p->gmres_batch.resize((size_t)nrhs);
+    for (int j = 0; j < nrhs; ++j) {
+        std::unique_ptr<GmresWorkspace> keep = std::move(p->gmres);
+        p->gmres = std::move(p->gmres_batch[(size_t)j]);
+        workspace(p, r.restart, need_vpin);
+        p->gmres_batch[(size_t)j] = std::move(p->gmres);
+        p->gmres = std::move(keep);
+    }
+    LSFC_HIP(hipStreamSynchronize(p->stream));
+    ApplyBatcher batcher; batcher.p = p; batcher.active = nrhs;
+    std::vector<std::exception_ptr> errs((size_t)nrhs);
+    std::vector<std::thread> th;
+    for (int j = 0; j < nrhs; ++j)
+        th.emplace_back([&, j] {
+            try {
+                LSFC_HIP(hipSetDevice(p->device));
+                Team T; T.root = p; T.batcher = &batcher;
+                GmresWorkspace* w = p->gmres_batch[(size_t)j].get();
+                T.mem.push_back({p, w, x + (int64_t)j * p->N, b + (int64_t)j * p->N});
+                T.rootw = w;
+                solve(T, opts_in, resnorm ? resnorm + (int64_t)j * cap : nullptr, cap, res + j, r.restart, r.maxiter, r.reltol, r.abstol, r.o);
+            } catch (...) { errs[(size_t)j] = std::current_exception(); }
+            batcher.leave();
+        });
+    for (auto& t : th) t.join();
+    LSFC_HIP(hipSetDevice(p->device));
+    LSFC_HIP(hipStreamSynchronize(p->stream));
+    for (auto& e : errs) if (e) std::rethrow_exception(e);
 }
 
 void gmres_run_multi(lsfc_plan* root, cplx* x_host, const cplx* b_host, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap,

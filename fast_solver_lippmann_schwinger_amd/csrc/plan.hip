@@ -251,8 +251,11 @@ void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
         const int pad2 = p->tuning.pad2 >= 0 ? p->tuning.pad2 : (big ? 72 : 0);
         p->pitch1 = p->pads[0] + ((p->ndim == 3) ? pad1 / 8 * 8 : 0);
         p->pitch2 = 8 * p->dims[2] + pad2 / 8 * 8;
-        p->A1.alloc((size_t)p->pitch1 * p->dims[1] * p->dims[2]);
-        if (p->ndim == 3) p->A2.alloc((size_t)p->pitch2 * p->pads[1] * (p->pads[0] / 8));
+        p->a1_elems = (int64_t)p->pitch1 * p->dims[1] * p->dims[2];
+        p->a2_elems = (p->ndim == 3) ? (int64_t)p->pitch2 * p->pads[1] * (p->pads[0] / 8) : 0;
+        p->A1.alloc((size_t)p->a1_elems);
+        if (p->ndim == 3) p->A2.alloc((size_t)p->a2_elems);
+        p->batch_cap = 1;
     } else {
         pw_scale(G2.p, scale, total, p->stream);
         LSFC_HIP(hipStreamSynchronize(p->stream));
@@ -328,6 +331,38 @@ void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
     }
 }
 
+void plan_convolve_batch_dev(lsfc_plan* p, int nrhs, const VecBatch& vb, bool use_nu, double alpha, double beta) {
+    LSFC_REQUIRE(nrhs >= 1 && nrhs <= LSFC_MAX_BATCH, "batch of %d right-hand sides (1..%d per pass)", nrhs, LSFC_MAX_BATCH);
+    if (nrhs == 1 || p->dist || p->multi || p->pipeline != lsfc_plan::PRUNED) {
+        for (int j = 0; j < nrhs; ++j) plan_convolve_dev(p, vb.x[j], vb.y[j], use_nu, alpha, beta);
+        return;
+    }
+    hipStream_t st = p->stream;
+    if (nrhs > p->batch_cap) {
+        // the work arrays hold the batch back to back: grow them (the plan is idle once its stream has drained)
+        LSFC_HIP(hipStreamSynchronize(st));
+        p->A1.alloc((size_t)(p->a1_elems * nrhs));
+        if (p->ndim == 3) p->A2.alloc((size_t)(p->a2_elems * nrhs));
+        p->batch_cap = nrhs;
+    }
+    const double* nu = use_nu ? p->nu.p : nullptr;
+    const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
+    const int m = p->dims[1], l = p->dims[2];
+    const int64_t nlines = (int64_t)m * l;
+    pruned_xfwd(Lx, p->tuning, vb, nrhs, p->a1_elems, nu, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st);
+    if (p->ndim == 3) {
+        const int p1 = p->pitch1, p2 = p->pitch2;
+        pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, p1, p2, st, nrhs, p->a1_elems, p->a2_elems);
+        pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, p->twl[2].p, Lx, Ly,
+                      (int64_t)p2 * Ly, (int64_t)p2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p,
+                      p->zmirror.p, l, st, nrhs, p->a2_elems);
+        pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p1, p2, st, nrhs, p->a1_elems, p->a2_elems);
+    } else {
+        pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, m, st, nrhs, p->a1_elems);
+    }
+    pruned_xinv(Lx, p->tuning, p->A1.p, vb, nrhs, p->a1_elems, alpha, beta, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st);
+}
+
 static void ensure_staging(lsfc_plan* p, int64_t count) {
     if (p->xs.n < (size_t)count) { p->xs.alloc((size_t)count); p->ys.alloc((size_t)count); }
 }
@@ -342,17 +377,26 @@ static void convolve_any(lsfc_plan* p, const double* x, double* y, int64_t nrhs,
         return;
     }
     LSFC_HIP(hipSetDevice(p->device));
+    // groups of up to LSFC_MAX_BATCH right-hand sides share one pass of the pipeline (one symbol read per group)
     if (memspace == LSFC_MEM_DEVICE) {
-        for (int64_t j = 0; j < nrhs; ++j)
-            plan_convolve_dev(p, (const cplx*)x + j * p->N, (cplx*)y + j * p->N, use_nu, alpha, beta);
+        for (int64_t j0 = 0; j0 < nrhs; j0 += LSFC_MAX_BATCH) {
+            const int cnt = (int)std::min<int64_t>(LSFC_MAX_BATCH, nrhs - j0);
+            VecBatch vb{};
+            for (int j = 0; j < cnt; ++j) { vb.x[j] = (const cplx*)x + (j0 + j) * p->N; vb.y[j] = (cplx*)y + (j0 + j) * p->N; }
+            plan_convolve_batch_dev(p, cnt, vb, use_nu, alpha, beta);
+        }
         return;
     }
     LSFC_REQUIRE(memspace == LSFC_MEM_HOST, "unknown memspace %d", memspace);
-    ensure_staging(p, p->N);
-    for (int64_t j = 0; j < nrhs; ++j) {
-        LSFC_HIP(hipMemcpyAsync(p->xs.p, (const cplx*)x + j * p->N, p->N * sizeof(cplx), hipMemcpyHostToDevice, p->stream));
-        plan_convolve_dev(p, p->xs.p, p->ys.p, use_nu, alpha, beta);
-        LSFC_HIP(hipMemcpyAsync((cplx*)y + j * p->N, p->ys.p, p->N * sizeof(cplx), hipMemcpyDeviceToHost, p->stream));
+    const int group = (int)std::min<int64_t>(LSFC_MAX_BATCH, nrhs);
+    ensure_staging(p, p->N * group);
+    for (int64_t j0 = 0; j0 < nrhs; j0 += group) {
+        const int cnt = (int)std::min<int64_t>(group, nrhs - j0);
+        LSFC_HIP(hipMemcpyAsync(p->xs.p, (const cplx*)x + j0 * p->N, (size_t)cnt * p->N * sizeof(cplx), hipMemcpyHostToDevice, p->stream));
+        VecBatch vb{};
+        for (int j = 0; j < cnt; ++j) { vb.x[j] = p->xs.p + (int64_t)j * p->N; vb.y[j] = p->ys.p + (int64_t)j * p->N; }
+        plan_convolve_batch_dev(p, cnt, vb, use_nu, alpha, beta);
+        LSFC_HIP(hipMemcpyAsync((cplx*)y + j0 * p->N, p->ys.p, (size_t)cnt * p->N * sizeof(cplx), hipMemcpyDeviceToHost, p->stream));
         LSFC_HIP(hipStreamSynchronize(p->stream));
     }
 }
@@ -602,6 +646,27 @@ int lsfc_gmres(lsfc_plan* plan, double* x, const double* b, const lsfc_gmres_opt
     });
     if (rc == LSFC_OK && conv_code != LSFC_OK) { set_last_error("gmres: maxiter reached without convergence"); return conv_code; }
     return rc;
+}
+
+int lsfc_gmres_batch(lsfc_plan* plan, double* x, const double* b, int64_t nrhs, const lsfc_gmres_opts* opts, double* resnorm,
+                     int64_t resnorm_cap, lsfc_gmres_result* results, int memspace) {
+    return guarded([&] {
+        LSFC_REQUIRE(plan && x && b && results, "NULL argument");
+        LSFC_REQUIRE(nrhs >= 1 && nrhs <= 64, "nrhs must be in 1..64");
+        LSFC_REQUIRE(!plan->multi && !plan->dist, "batched GMRES runs on a single-device plan");
+        LSFC_HIP(hipSetDevice(plan->device));
+        if (memspace == LSFC_MEM_DEVICE) {
+            gmres_run_batch(plan, (cplx*)x, (const cplx*)b, (int)nrhs, opts, resnorm, resnorm_cap, results);
+        } else {
+            LSFC_REQUIRE(memspace == LSFC_MEM_HOST, "unknown memspace %d", memspace);
+            const size_t bytes = (size_t)nrhs * plan->N * sizeof(cplx);
+            DevBuf<cplx> xd, bd; xd.alloc((size_t)nrhs * plan->N); bd.alloc((size_t)nrhs * plan->N);
+            LSFC_HIP(hipMemcpy(xd.p, x, bytes, hipMemcpyHostToDevice));
+            LSFC_HIP(hipMemcpy(bd.p, b, bytes, hipMemcpyHostToDevice));
+            gmres_run_batch(plan, xd.p, bd.p, (int)nrhs, opts, resnorm, resnorm_cap, results);
+            LSFC_HIP(hipMemcpy(x, xd.p, bytes, hipMemcpyDeviceToHost));
+        }
+    });
 }
 
 int lsfc_plan_set_stream(lsfc_plan* plan, void* hip_stream) {

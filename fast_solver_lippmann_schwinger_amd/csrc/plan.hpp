@@ -107,6 +107,10 @@ struct lsfc_plan {
     int sym_hz = 0;
     lsfc::DevBuf<int> zmirror;
     int pitch1 = 0, pitch2 = 0;      // row pitch of A1 (>= Lx) and of one storage-y row of an A2 tile (>= 8*l)
+    // several right-hand sides per launch (lsfc_apply_batch, lsfc_gmres_batch): A1 / A2 hold batch_cap members of
+    // a1_elems / a2_elems entries back to back (grown on demand)
+    int64_t a1_elems = 0, a2_elems = 0;
+    int batch_cap = 1;
 
     // rocFFT pipelines
     std::unique_ptr<lsfc::RocFft> fwd, inv;
@@ -120,6 +124,7 @@ struct lsfc_plan {
     lsfc::DevBuf<lsfc::cplx> xs, ys;
 
     std::unique_ptr<lsfc::GmresWorkspace> gmres;
+    std::vector<std::unique_ptr<lsfc::GmresWorkspace>> gmres_batch;    // one workspace per right-hand side of lsfc_gmres_batch
     std::unique_ptr<lsfc::DistState> dist;
     std::unique_ptr<lsfc::MultiState> multi;
 
@@ -131,6 +136,9 @@ namespace lsfc {
 
 // y = alpha*x + beta*conv((use_nu ? nu : 1) .* x); device pointers, stream-ordered.
 void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta);
+// nrhs <= LSFC_MAX_BATCH right-hand sides in one pass of the pipeline: y_j = alpha*x_j + beta*conv(...x_j); the symbol is read
+// once per batch in the fused pass (pruned pipeline; the other pipelines run the members one after the other)
+void plan_convolve_batch_dev(lsfc_plan* p, int nrhs, const VecBatch& vb, bool use_nu, double alpha, double beta);
 // the operator M = I + omega^2 G nu
 inline void plan_apply_dev(lsfc_plan* p, const cplx* x, cplx* y) { plan_convolve_dev(p, x, y, true, 1.0, p->omega * p->omega); }
 
@@ -174,6 +182,10 @@ void multi_profile(lsfc_plan* root, int reps, int max_stages, const char** names
 // GMRES (gmres.hip)
 void gmres_run(lsfc_plan* p, cplx* x_dev, const cplx* b_dev, const lsfc_gmres_opts* opts, double* resnorm, int64_t cap,
                lsfc_gmres_result* res);
+// nrhs independent solves in lock step (device vectors back to back, nrhs <= 64): every Arnoldi step applies the operator
+// to all unconverged right-hand sides in one batch
+void gmres_run_batch(lsfc_plan* p, cplx* x_dev, const cplx* b_dev, int nrhs, const lsfc_gmres_opts* opts, double* resnorm, int64_t cap,
+                     lsfc_gmres_result* res);
 // multi-device plan: x (in/out) and b are HOST vectors of the full size; the Krylov basis is spread over the devices
 void gmres_run_multi(lsfc_plan* root, cplx* x_host, const cplx* b_host, const lsfc_gmres_opts* opts, double* resnorm, int64_t cap,
                      lsfc_gmres_result* res);

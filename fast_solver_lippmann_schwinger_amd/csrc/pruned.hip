@@ -6,12 +6,12 @@
 namespace lsfc {
 
 #define LSFC_FAMILY_DECLS(F)                                                                                                   \
-    void pruned_xfwd_f##F(int, const PrunedTuning&, const cplx*, const double*, cplx*, const cplx*, int64_t, int, int, int, hipStream_t, int64_t); \
-    void pruned_xinv_f##F(int, const PrunedTuning&, const cplx*, const cplx*, cplx*, double, double, const cplx*, int64_t, int, int, int, hipStream_t, int64_t); \
-    void pruned_yfwd_f##F(int, const PrunedTuning&, const cplx*, cplx*, const cplx*, int, int, int, int, int, hipStream_t);     \
-    void pruned_yinv_f##F(int, const PrunedTuning&, const cplx*, cplx*, const cplx*, int, int, int, int, int, hipStream_t);     \
+    void pruned_xfwd_f##F(int, const PrunedTuning&, const VecBatch&, int, int64_t, const double*, cplx*, const cplx*, int64_t, int, int, int, hipStream_t, int64_t); \
+    void pruned_xinv_f##F(int, const PrunedTuning&, const cplx*, const VecBatch&, int, int64_t, double, double, const cplx*, int64_t, int, int, int, hipStream_t, int64_t); \
+    void pruned_yfwd_f##F(int, const PrunedTuning&, const cplx*, cplx*, const cplx*, int, int, int, int, int, hipStream_t, int, int64_t, int64_t);     \
+    void pruned_yinv_f##F(int, const PrunedTuning&, const cplx*, cplx*, const cplx*, int, int, int, int, int, hipStream_t, int, int64_t, int64_t);     \
     void pruned_zfused_f##F(int, const PrunedTuning&, cplx*, const cplx*, const cplx*, const cplx*, int, int, int64_t, int64_t, int64_t, \
-                            int64_t, int64_t, int64_t, const int2*, const int*, int, hipStream_t);                              \
+                            int64_t, int64_t, int64_t, const int2*, const int*, int, hipStream_t, int, int64_t);                \
     void pruned_perm_f##F(int, int*);                                                                                           \
     int pruned_twfull_len_f##F(int);                                                                                            \
     void pruned_twfull_f##F(int, const cplx*, cplx*);
@@ -45,22 +45,24 @@ int pruned_best_length(int64_t n) {
     case 5: NAME##_f5(__VA_ARGS__); break;                                  \
     default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); }
 
-void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
-    LSFC_ROUTE(L, pruned_xfwd, L, tn, x, nu, out, tw, nlines, W, Wp, n, st, bstride);
+void pruned_xfwd(int L, const PrunedTuning& tn, const VecBatch& vb, int nrhs, int64_t obatch, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
+    LSFC_REQUIRE(nrhs >= 1 && nrhs <= LSFC_MAX_BATCH, "batch of %d right-hand sides (1..%d per launch)", nrhs, LSFC_MAX_BATCH);
+    LSFC_ROUTE(L, pruned_xfwd, L, tn, vb, nrhs, obatch, nu, out, tw, nlines, W, Wp, n, st, bstride);
 }
-void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xo, cplx* y, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
-    LSFC_ROUTE(L, pruned_xinv, L, tn, in, xo, y, alpha, beta, tw, nlines, W, Wp, n, st, bstride);
+void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const VecBatch& vb, int nrhs, int64_t ibatch, double alpha, double beta, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
+    LSFC_REQUIRE(nrhs >= 1 && nrhs <= LSFC_MAX_BATCH, "batch of %d right-hand sides (1..%d per launch)", nrhs, LSFC_MAX_BATCH);
+    LSFC_ROUTE(L, pruned_xinv, L, tn, in, vb, nrhs, ibatch, alpha, beta, tw, nlines, W, Wp, n, st, bstride);
 }
-void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
-    LSFC_ROUTE(L, pruned_yfwd, L, tn, a1, a2, tw, Lx, m, l, p1, p2, st);
+void pruned_yfwd(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st, int nrhs, int64_t b1, int64_t b2) {
+    LSFC_ROUTE(L, pruned_yfwd, L, tn, a1, a2, tw, Lx, m, l, p1, p2, st, nrhs, b1, b2);
 }
-void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st) {
-    LSFC_ROUTE(L, pruned_yinv, L, tn, a2, a1, tw, Lx, m, l, p1, p2, st);
+void pruned_yinv(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st, int nrhs, int64_t b1, int64_t b2) {
+    LSFC_ROUTE(L, pruned_yinv, L, tn, a2, a1, tw, Lx, m, l, p1, p2, st, nrhs, b1, b2);
 }
 void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine, const int2* ytab,
-                   const int* zm, int nin, hipStream_t st) {
-    LSFC_ROUTE(L, pruned_zfused, L, tn, data, sym, tw, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
+                   const int* zm, int nin, hipStream_t st, int nrhs, int64_t dBatch) {
+    LSFC_ROUTE(L, pruned_zfused, L, tn, data, sym, tw, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, nrhs, dBatch);
 }
 void pruned_perm(int L, int* freq_of_storage) { LSFC_ROUTE(L, pruned_perm, L, freq_of_storage); }
 int pruned_twfull_len(int L) {

@@ -4,6 +4,15 @@
 
 namespace lsfc {
 
+// Several right-hand sides through one pipeline (lsfc_apply_batch, the batched GMRES): the x passes take the user
+// vectors of all of them (arbitrary pointers), the work arrays hold the batch back to back, and the fused pass loads
+// every symbol tile ONCE for the whole batch.
+static constexpr int LSFC_MAX_BATCH = 8;
+struct VecBatch {
+    const cplx* x[LSFC_MAX_BATCH];
+    cplx* y[LSFC_MAX_BATCH];
+};
+
 struct PrunedTuning {
     bool split_x = true;   // contiguous (x) passes: exchange re/im separately (half the LDS, twice the barriers)
     bool split_s = true;   // strided y passes
@@ -27,13 +36,27 @@ int pruned_best_length(int64_t n);
 void pruned_perm(int L, int* freq_of_storage);
 PrunedTuning pruned_default_tuning();
 
-void pruned_xfwd(int L, const PrunedTuning&, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t,
+// nrhs / vb / *batch: right-hand sides per launch (<= LSFC_MAX_BATCH), their vectors, and the distance between the
+// batch members in the work arrays
+void pruned_xfwd(int L, const PrunedTuning&, const VecBatch& vb, int nrhs, int64_t obatch, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t,
                  int64_t bstride = 0);     // bstride: distance between chunks of the storage axis (0: dense, Wp * nlines)
-void pruned_xinv(int L, const PrunedTuning&, const cplx* in, const cplx* xorig, cplx* y, double alpha, double beta,
+void pruned_xinv(int L, const PrunedTuning&, const cplx* in, const VecBatch& vb, int nrhs, int64_t ibatch, double alpha, double beta,
                  const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t, int64_t bstride = 0);
+inline void pruned_xfwd(int L, const PrunedTuning& tn, const cplx* x, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st,
+                        int64_t bstride = 0) {
+    VecBatch vb{}; vb.x[0] = x;
+    pruned_xfwd(L, tn, vb, 1, 0, nu, out, tw, nlines, W, Wp, n, st, bstride);
+}
+inline void pruned_xinv(int L, const PrunedTuning& tn, const cplx* in, const cplx* xorig, cplx* y, double alpha, double beta,
+                        const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride = 0) {
+    VecBatch vb{}; vb.x[0] = xorig; vb.y[0] = y;
+    pruned_xinv(L, tn, in, vb, 1, 0, alpha, beta, tw, nlines, W, Wp, n, st, bstride);
+}
 // p1: row pitch of A1 (>= Lx), p2: pitch of one storage-y row of an A2 tile (>= 8*l); both multiples of 8 elements
-void pruned_yfwd(int L, const PrunedTuning&, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);
-void pruned_yinv(int L, const PrunedTuning&, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t);
+void pruned_yfwd(int L, const PrunedTuning&, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t,
+                 int nrhs = 1, int64_t batch1 = 0, int64_t batch2 = 0);
+void pruned_yinv(int L, const PrunedTuning&, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t,
+                 int nrhs = 1, int64_t batch1 = 0, int64_t batch2 = 0);
 // full stage-twiddle table of the factorisation used for length L (host side; tw[j] = exp(-2 pi i j / L))
 int pruned_twfull_len(int L);
 void pruned_twfull(int L, const cplx* tw, cplx* out);
@@ -41,6 +64,7 @@ void pruned_zfused(int L, const PrunedTuning&, cplx* data, const cplx* sym, cons
                    int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
                    const int2* ytab /* block order -> (data row, symbol row); NULL: identity */,
                    const int* zm /* z-even symbol: partner storage index of every upper-half slot; NULL: full symbol lines */,
-                   int nin /* valid entries per line (<= L/2) */, hipStream_t);
+                   int nin /* valid entries per line (<= L/2) */, hipStream_t,
+                   int nrhs = 1, int64_t dBatch = 0 /* distance between the batch members in `data` */);
 
 } // namespace lsfc

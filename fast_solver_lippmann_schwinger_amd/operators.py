@@ -413,6 +413,78 @@ def gmres_(x, A, b, Pl=None, abstol=0.0, reltol=None, restart=None, maxiter=None
     return x
 
 
+def apply_batch(M, B, mode=0):
+    """Rows of B (nrhs, N) through the operator in batched passes (lsfc_apply_batch): mode 0 ``M * b``, 1 bare
+    convolution, 2 convolution of nu .* b.  The multi-vector form of src/FastConvolution3D.jl:146-159."""
+    if _is_torch(B):
+        nrhs = B.shape[0]
+        pb, sb, keep = _vec(B.reshape(-1), M.N, "B", count=nrhs, plan=M._plan)
+        import torch
+        Y = torch.empty_like(keep)
+        L.check(L.load().lsfc_apply_batch(M._plan, pb, C.c_void_p(Y.data_ptr()), nrhs, mode, sb))
+        return Y.reshape(nrhs, M.N)
+    B = np.ascontiguousarray(B, dtype=np.complex128)
+    if B.ndim != 2 or B.shape[1] != M.N:
+        raise ValueError(f"DimensionMismatch: B must be (nrhs, {M.N})")
+    Y = np.empty_like(B)
+    L.check(L.load().lsfc_apply_batch(M._plan, B.ctypes.data_as(C.c_void_p), Y.ctypes.data_as(C.c_void_p), B.shape[0], mode, L.LSFC_MEM_HOST))
+    return Y
+
+
+def gmres_batch_(X, A, B, Pl=None, abstol=0.0, reltol=None, restart=None, maxiter=None, log=False,
+                 initially_zero=False, orth_meth="ModifiedGramSchmidt"):
+    """``gmres!`` for several right-hand sides at once (rows of B, solutions in the rows of X, updated in place): the
+    solves of tests/plasma_example.jl:160-176 (two incident directions, one after the other in the reference) run in
+    lock step, one batched operator application per Arnoldi step.  Each row's iterates are those of ``gmres_`` on that
+    row alone.  Returns X or (X, [ConvergenceHistory per row])."""
+    torch_in = _is_torch(X)
+    if torch_in:
+        nrhs = X.shape[0]
+        px, sx, keepx = _vec(X.reshape(-1), A.N, "X", count=nrhs, plan=A._plan)
+        pb, sb, keepb = _vec(B.reshape(-1), A.N, "B", count=nrhs)
+        if keepx.data_ptr() != X.data_ptr():
+            raise TypeError("X must be contiguous (it is updated in place)")
+    else:
+        if not (isinstance(X, np.ndarray) and X.dtype == np.complex128 and X.flags.c_contiguous and X.ndim == 2 and X.shape[1] == A.N):
+            raise TypeError(f"X must be a C-contiguous complex128 array of shape (nrhs, {A.N}) (it is updated in place)")
+        nrhs = X.shape[0]
+        Bc = np.ascontiguousarray(B, dtype=np.complex128)
+        if Bc.shape != X.shape:
+            raise ValueError("DimensionMismatch: B")
+        px, sx, pb, sb, keepb = X.ctypes.data_as(C.c_void_p), L.LSFC_MEM_HOST, Bc.ctypes.data_as(C.c_void_p), L.LSFC_MEM_HOST, Bc
+    if sx != sb:
+        raise TypeError("X and B must live in the same memory space")
+    opts = L.GmresOpts()
+    opts.restart = int(restart) if restart is not None else 0
+    opts.maxiter = int(maxiter) if maxiter is not None else 0
+    opts.reltol = float(reltol) if reltol is not None else -1.0
+    opts.abstol = float(abstol)
+    opts.orth = _ORTH[orth_meth]
+    opts.initially_zero = 1 if initially_zero else 0
+    err = []
+    if Pl is not None:
+        def _cb(user, v, n):
+            try:
+                Pl(np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_double)), shape=(2 * n,)).view(np.complex128))
+                return 0
+            except Exception as e:
+                err.append(e)
+                return 1
+        cb = L.PRECOND_FN(_cb)
+        opts.precond = cb
+    cap = max(1, min(int(maxiter) if maxiter is not None else A.N, 1 << 20))
+    res = (L.GmresResult * nrhs)()
+    resnorm = np.zeros((nrhs, cap), dtype=np.float64)
+    rc = L.load().lsfc_gmres_batch(A._plan, px, pb, nrhs, C.byref(opts), resnorm.ctypes.data_as(C.c_void_p), cap, res, sx)
+    if err:
+        raise err[0]
+    L.check(rc)
+    if log:
+        return X, [ConvergenceHistory(resnorm[j, :min(res[j].iters, cap)].copy(), int(res[j].iters), int(res[j].mvps), bool(res[j].converged))
+                   for j in range(nrhs)]
+    return X
+
+
 # ---------------------------------------------------------------------------
 # timing helpers used by bench.py (HIP events on the plan's own stream)
 # ---------------------------------------------------------------------------

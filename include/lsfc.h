@@ -131,8 +131,12 @@ int lsfc_apply(lsfc_plan* plan, const double* x, double* y, int memspace);
  * apply_nu accordingly. */
 int lsfc_convolve(lsfc_plan* plan, const double* x, double* y, int apply_nu, int memspace);
 
-/* nrhs independent applies, vectors stored back to back (x + j*N).  Serves the
- * multi-source callers (sampleG3D, src/FastConvolution3D.jl:136-160). */
+/* nrhs independent applies, vectors stored back to back (x + j*N).  Serves the multi-source callers (sampleG3D applies
+ * the operator to up to 27 unit vectors at a time, src/FastConvolution3D.jl:146-159) and several incident fields
+ * (tests/plasma_example.jl:160-176).  Groups of up to 8 right-hand sides go through ONE pass of the pipeline: the x and
+ * y passes run all of them per launch and the fused pass loads each tile of the Green's symbol once per group, so the
+ * symbol's share of the HBM traffic (8 of the 35 complex per point in the byte model) is paid once per group instead of
+ * once per vector, and small grids amortise their launch latency. */
 int lsfc_apply_batch(lsfc_plan* plan, const double* x, double* y, int64_t nrhs, int mode /*0 apply,1 convolve,2 convolve+nu*/, int memspace);
 
 /* Rows of the discrete Green's matrix for the delta sources at grid indices sources[0..nsrc): out + s*N receives
@@ -179,6 +183,16 @@ typedef struct lsfc_gmres_result {
  * receives up to resnorm_cap entries of history[:resnorm]. */
 int lsfc_gmres(lsfc_plan* plan, double* x, const double* b, const lsfc_gmres_opts* opts,
                double* resnorm, int64_t resnorm_cap, lsfc_gmres_result* result, int memspace);
+
+/* nrhs independent solves of the same operator in lock step (x, b: nrhs vectors back to back; resnorm: nrhs rows of
+ * resnorm_cap entries; results[nrhs]).  Replaces the back-to-back gmres! calls for several incident directions
+ * (tests/plasma_example.jl:160-176): each right-hand side keeps its own Krylov basis, Hessenberg matrix and stopping
+ * test -- its iterates are those of lsfc_gmres on that right-hand side alone -- but every Arnoldi step applies the
+ * operator to all unconverged right-hand sides in one batched pass (see lsfc_apply_batch).  Host preconditioner
+ * callbacks are invoked one at a time.  Returns LSFC_OK even if some right-hand side hit maxiter: check
+ * results[j].converged. */
+int lsfc_gmres_batch(lsfc_plan* plan, double* x, const double* b, int64_t nrhs, const lsfc_gmres_opts* opts,
+                     double* resnorm, int64_t resnorm_cap, lsfc_gmres_result* results, int memspace);
 
 /* ---- device-resident SparsifyingPreconditioner apply ------------------------ */
 

@@ -365,12 +365,12 @@ def test_error_paths_and_edge_cases(lsfc):
     assert lib.lsfc_plan_set_tuning(M._plan, b"nonsense", 1) == -1
     src = np.array([n ** 3], dtype=np.int64); out = np.empty(n ** 3, complex)
     assert lib.lsfc_sample_sources(M._plan, src.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p), 0) == -1
-    # batch entry == repeated single applies; zero vector maps to zero; smallest supported pruned grid is n = 16
+    # batch entry (one fused pass for the three vectors) vs single applies; zero vector maps to zero
     X = np.stack([b, 2j * b, np.zeros_like(b)])
     Y = np.empty_like(X)
     L.check(lib.lsfc_apply_batch(M._plan, X.ctypes.data_as(C.c_void_p), Y.ctypes.data_as(C.c_void_p), 3, 0, 0))
     y = M * b
-    assert np.array_equal(Y[0], y) and rel_err(Y[1], 2j * y) < 1e-15 and not Y[2].any()
+    assert rel_err(Y[0], y) < 1e-14 and rel_err(Y[1], 2j * y) < 1e-14 and not Y[2].any()
     # n = 8 (padded length 16) is below the hand-written range: the rocFFT pipeline takes over, same results
     n8 = 8
     rng = np.random.default_rng(2)
