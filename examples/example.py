@@ -29,6 +29,9 @@ def main(h=0.005, quadRule="Greengard_Vico"):
     Y = np.repeat(y[None, :], n, axis=0).reshape(-1, order="F")                      # :40
     fastconv = ls.buildFastConvolution(x, y, h, k, nu, quadRule=quadRule)            # :54
     print(f"n = {n}, N = {n * m}, pipeline {fastconv.pipeline}, padded grid {fastconv.padded_dims[:2]}")
+    # wrapper for linear maps (:56-61): apply_conv!(x) = fastconvolution(fastconv, x); LinearMap(apply_conv!, N)
+    from scipy.sparse.linalg import LinearOperator
+    convolution_map = LinearOperator((n * m, n * m), matvec=lambda v: ls.fastconvolution(fastconv, v), dtype=np.complex128)
     u_inc = np.exp(1j * k * X)                      # :76
     rhs = -k**2 * ls.FFTconvolution(fastconv, nu(X, Y) * u_inc)                      # :77
     u = np.zeros(n * m, dtype=np.complex128)
@@ -60,6 +63,16 @@ def main(h=0.005, quadRule="Greengard_Vico"):
     u3, info3 = ls.gmres_(u3, fastconv, rhs, Pl=precond, maxiter=60, log=True)
     print(f"gmres with the sparsifying stand-in applied on the device (it has the structure of the reference's pair, not its\n"
           f"quality: a 5-point Laplacian on a Dirichlet box): {info3.iters} iterations, {precond.stats()}")
+    # two incident directions (tests/plasma_example.jl:160-176 solves them one after the other): here in lock step, one
+    # batched operator application per Arnoldi step
+    U_inc = np.stack([u_inc, np.exp(1j * k * Y)])
+    RHS = -k**2 * ls.apply_batch(fastconv, nu(X, Y) * U_inc, 1)
+    UU = np.zeros_like(RHS)
+    t0 = time.time()
+    UU, infos = ls.gmres_batch_(UU, fastconv, RHS, log=True)
+    print(f"two incident directions in one batch: {[i.iters for i in infos]} iterations, {time.time() - t0:.3f} s; "
+          f"|u_batch - u|/|u| = {np.linalg.norm(UU[0] - u) / np.linalg.norm(u):.2e}; "
+          f"LinearMap check |L*u - M*u| = {np.linalg.norm(convolution_map @ u - fastconv * u):.1e}")
     return (u + u_inc).reshape((n, m), order="F"), info     # :98, total field
 
 

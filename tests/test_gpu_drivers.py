@@ -1,0 +1,185 @@
+"""Driver parity harness: the reference's two driver scripts at THEIR sizes --
+examples/example.jl (2D, h = 0.005, k = 200, n = 201, Greengard-Vico) and examples/example3D.jl (3D, n = 48, k = 48) --
+run over the mirror and compared ENTRY BY ENTRY with the oracle's GMRES on the same inputs: right-hand side, residual
+history without and with a left preconditioner applied through the host in-place callback (the two-argument ldiv! of
+src/preconditioner.jl:147-170; stand-in Msp / As pair of the reference's structure -- the real assembly is out of scope),
+two incident directions solved as one batch (tests/plasma_example.jl:160-176), the LinearMap wrapper of
+examples/example.jl:56-61, and the total field."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from oracle import lsfc_oracle as o
+import cases
+from cases import TOL
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "examples", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _history_close(r, ro, tol_rel, label):
+    r, ro = np.asarray(r), np.asarray(ro)
+    assert abs(len(r) - len(ro)) <= 1, (label, len(r), len(ro))
+    kk = min(len(r), len(ro))
+    big = ro[:kk] > 1e3 * tol_rel * ro[0]
+    assert big.sum() >= 3, label
+    worst = np.max(np.abs(r[:kk] - ro[:kk])[big] / ro[:kk][big])
+    assert worst < 1e-6, (label, worst)
+    return worst
+
+
+@pytest.fixture(scope="module")
+def ex2d(lsfc):
+    h = 0.005                                      # examples/example.jl:30-40
+    k = 1.0 / h
+    n = 201
+    x = -0.5 + h * np.arange(n)
+    M = lsfc.buildFastConvolution(x, x, h, k, o.gaussian_bump, quadRule="Greengard_Vico")       # :54
+    Mo = o.build_fast_convolution(x, x, h, k, o.gaussian_bump, quadRule="Greengard_Vico")
+    X, Y = o.grid2d(x, x)
+    return dict(h=h, k=k, n=n, x=x, M=M, Mo=Mo, X=X, Y=Y, nu=o.gaussian_bump(X, Y))
+
+
+def test_example_2d_reference_size_rhs_and_gmres_history(lsfc, ex2d):
+    M, Mo, k, X, nu = ex2d["M"], ex2d["Mo"], ex2d["k"], ex2d["X"], ex2d["nu"]
+    assert M.pipeline == "pruned-hip"
+    A = lambda v: o.fastconvolution(Mo, v)
+    u_inc = np.exp(1j * k * X)                                              # :76
+    rhs = -k ** 2 * lsfc.FFTconvolution(M, nu * u_inc)                      # :77
+    assert rel_err(rhs, -k ** 2 * o.fft_convolution(Mo, nu * u_inc)) < TOL
+    # gmres!(u, fastconv, rhs, log=true) (:91): defaults restart 20, reltol sqrt(eps)
+    u = np.zeros(M.N, complex)
+    u, info = lsfc.gmres_(u, M, rhs, log=True)
+    uo = np.zeros(M.N, complex)
+    uo, ho = o.gmres(uo, A, rhs)
+    assert info.isconverged and ho.isconverged and abs(info.iters - ho.iters) <= 1
+    _history_close(info["resnorm"], ho.resnorm, np.sqrt(np.finfo(float).eps), "example.jl:91")
+    assert rel_err(u, uo) < 1e-6
+    assert np.linalg.norm(A(u) - rhs) / np.linalg.norm(rhs) < 5e-8           # true residual with the ORACLE apply
+    assert rel_err(u + u_inc, uo + u_inc) < 1e-6                             # total field (:98)
+    ex2d["rhs"], ex2d["u"], ex2d["info"] = rhs, u, info
+
+
+def test_example_2d_left_preconditioner_through_host_callback(lsfc, ex2d):
+    # gmres!(u, fastconv, rhs, Pl=precond, log=true) (:85): precond = SparsifyingPreconditioner(Msp, As), applied on the
+    # HOST by the in-place callback, once per Arnoldi step -- and the same object applied on the device
+    M, Mo, k, X, nu, n, h = ex2d["M"], ex2d["Mo"], ex2d["k"], ex2d["X"], ex2d["nu"], ex2d["n"], ex2d["h"]
+    A = lambda v: o.fastconvolution(Mo, v)
+    rhs = ex2d.get("rhs")
+    if rhs is None:
+        rhs = -k ** 2 * lsfc.FFTconvolution(M, nu * np.exp(1j * k * X))
+    Msp, As = cases.sparsifying_pair_2d(n, h, k, nu)
+    P = o.SparsifyingPreconditioner(Msp, As)                                 # host sparse LU (src/preconditioner.jl:35)
+    calls = []
+
+    def Pl(v):
+        calls.append(1)
+        P.ldiv_(v)                                                           # ldiv!(P, v), :147-170
+
+    u = np.zeros(M.N, complex)
+    u, info = lsfc.gmres_(u, M, rhs, Pl=Pl, maxiter=40, log=True)
+    assert len(calls) == info.mvps + 1
+    uo = np.zeros(M.N, complex)
+    uo, ho = o.gmres(uo, A, rhs, Pl=P.solve, maxiter=40)
+    assert info.iters == ho.iters == 40 or (info.isconverged and ho.isconverged)
+    _history_close(info["resnorm"], ho.resnorm, np.sqrt(np.finfo(float).eps), "example.jl:85 host callback")
+    assert rel_err(u, uo) < 1e-6
+    # the device-resident apply of the same preconditioner follows the same iterates
+    Pd = lsfc.SparsifyingPreconditioner(Msp, As)
+    ud = np.zeros(M.N, complex)
+    ud, infod = lsfc.gmres_(ud, M, rhs, Pl=Pd, maxiter=40, log=True)
+    _history_close(infod["resnorm"], ho.resnorm, np.sqrt(np.finfo(float).eps), "example.jl:85 device preconditioner")
+    assert rel_err(ud, uo) < 1e-6
+
+
+def test_example_2d_two_incident_directions_as_one_batch(lsfc, ex2d):
+    M, Mo, k, X, Y, nu = ex2d["M"], ex2d["Mo"], ex2d["k"], ex2d["X"], ex2d["Y"], ex2d["nu"]
+    A = lambda v: o.fastconvolution(Mo, v)
+    U_inc = np.stack([np.exp(1j * k * X), np.exp(1j * k * Y)])
+    RHS = -k ** 2 * lsfc.apply_batch(M, nu * U_inc, 1)
+    for j in range(2):
+        assert rel_err(RHS[j], -k ** 2 * o.fft_convolution(Mo, nu * U_inc[j])) < TOL
+    UU = np.zeros_like(RHS)
+    UU, infos = lsfc.gmres_batch_(UU, M, RHS, log=True)
+    for j in range(2):
+        uo = np.zeros(M.N, complex)
+        uo, ho = o.gmres(uo, A, RHS[j])
+        assert infos[j].isconverged and abs(infos[j].iters - ho.iters) <= 1
+        _history_close(infos[j]["resnorm"], ho.resnorm, np.sqrt(np.finfo(float).eps), f"direction {j}")
+        assert rel_err(UU[j], uo) < 1e-6
+
+
+def test_example_2d_linear_map_wrapper(lsfc, ex2d):
+    # examples/example.jl:56-61: convolution_map = LinearMap(apply_conv!, 40401; issymmetric=false, ismutating=false) with
+    # apply_conv!(x) = fastconvolution(fastconv, x).  scipy's LinearOperator is that wrapper; a generic Krylov solver
+    # that only knows `matvec` (scipy.sparse.linalg.gmres, standing in for IterativeSolvers on a LinearMap) solves the same system.
+    import scipy.sparse.linalg as spla
+    M, Mo, k, X, nu = ex2d["M"], ex2d["Mo"], ex2d["k"], ex2d["X"], ex2d["nu"]
+    N = M.N
+    assert N == 40401 and M.shape == (N, N) and M.dtype == np.complex128 and M.size(2) == N
+    Lop = spla.LinearOperator(M.shape, matvec=M.matvec, dtype=M.dtype)
+    b = o.random_vector(N)
+    assert rel_err(Lop @ b, o.fastconvolution(Mo, b)) < TOL
+    assert rel_err(Lop.matvec(b), M * b) == 0.0
+    Lfree = spla.LinearOperator((N, N), matvec=lambda v: lsfc.fastconvolution(M, v), dtype=np.complex128)       # apply_conv!
+    rhs = -k ** 2 * lsfc.FFTconvolution(M, nu * np.exp(1j * k * X))
+    us, code = spla.gmres(Lfree, rhs, restart=20, rtol=1e-8, maxiter=50)
+    assert code == 0
+    u = np.zeros(N, complex)
+    u, info = lsfc.gmres_(u, M, rhs, reltol=1e-8, log=True)
+    assert info.isconverged and rel_err(us, u) < 1e-6
+    assert np.linalg.norm(o.fastconvolution(Mo, us) - rhs) / np.linalg.norm(rhs) < 2e-8
+
+
+def test_example_3d_reference_size_history_and_total_field(lsfc):
+    # examples/example3D.jl:20-31, 54, 71-79 at its own size: n = 48, k = 48
+    n = 48
+    x, h = cases.grid(n, False)
+    k = 1.0 / h
+    X, Y, Z = o.grid3d(x, x, x)
+    M = lsfc.buildFastConvolution3D(x, x, x, X, Y, Z, h, k, o.gaussian_bump)                      # :54
+    assert M.pipeline == "pruned-hip" and M.padded_dims == (96, 96, 96)
+    nu = o.gaussian_bump(X, Y, Z)
+    G2 = o.reduced_symbol_gv3d(n, n, n, 1.0, k, patch_singular=False)
+    A = lambda v: o.apply_reduced(G2, nu, k, v, (n, n, n))
+    u_inc = np.exp(1j * k * X)                                               # :71
+    rhs = -(M * u_inc - u_inc)                                               # :72
+    assert rel_err(rhs, -(A(u_inc) - u_inc)) < TOL
+    u = np.zeros(n ** 3, complex)
+    u, info = lsfc.gmres_(u, M, rhs, log=True)                               # :78 (no Pl: the reference's is out of scope)
+    uo = np.zeros(n ** 3, complex)
+    uo, ho = o.gmres(uo, A, rhs)
+    assert info.isconverged and ho.isconverged and abs(info.iters - ho.iters) <= 1
+    _history_close(info["resnorm"], ho.resnorm, np.sqrt(np.finfo(float).eps), "example3D.jl:78")
+    assert rel_err(u + u_inc, uo + u_inc) < 1e-6                             # :85 total field
+    # two incident directions as one batch; the host callback path at this size
+    U_inc = np.stack([u_inc, np.exp(1j * k * Z)])
+    RHS = -(lsfc.apply_batch(M, U_inc, 0) - U_inc)
+    UU = np.zeros_like(RHS)
+    d = 1.0 + k ** 2 * 0.01 * nu
+    UU, infos = lsfc.gmres_batch_(UU, M, RHS, Pl=lambda v: v.__itruediv__(d), log=True)
+    for j in range(2):
+        uj = np.zeros(n ** 3, complex)
+        uj, hj = o.gmres(uj, A, RHS[j], Pl=lambda v: v / d)
+        assert infos[j].isconverged and abs(infos[j].iters - hj.iters) <= 1
+        _history_close(infos[j]["resnorm"], hj.resnorm, np.sqrt(np.finfo(float).eps), f"3D direction {j}")
+        assert rel_err(UU[j], uj) < 1e-6
+    M.close()
+
+
+def test_example_scripts_run_at_reference_sizes(lsfc, capsys):
+    # the scripts themselves, as a user would run them (examples/example.jl, examples/example3D.jl)
+    U, info = _load("example").main(0.005)
+    assert U.shape == (201, 201) and info.isconverged and np.isfinite(U).all()
+    U3, info3 = _load("example3D").main(48)
+    assert U3.shape == (48, 48, 48) and info3.isconverged and np.isfinite(U3).all()
