@@ -50,13 +50,13 @@ def main(h=0.005, quadRule="Greengard_Vico"):
     print(f"gmres with Pl: {info2.iters} iterations; |u - u2|/|u| = {np.linalg.norm(u - u2) / np.linalg.norm(u):.2e}")
     # precond = SparsifyingPreconditioner(Msp, As); gmres!(u, fastconv, rhs, Pl=precond) (:80-86): the same object with its
     # apply on the device.  The reference assembles (Msp, As) in src/SparsifyingMatrix2D.jl, which is outside this
-    # package: a stand-in pair of the same structure is used here -- As = -(Lap_h + k^2 + i eps) sparsifies
+    # package: a stand-in pair of the same structure is used here -- As = -(Lap_h + (1 + 0.2i) k^2) sparsifies
     # I + k^2 G nu into Msp = As + k^2 diag(nu), because (Lap + k^2) G = -delta.
     import scipy.sparse as sp
     e = np.ones(n)
     T = sp.diags([e[:-1], -2 * e, e[:-1]], [-1, 0, 1]) / h**2
     lap = sp.kron(sp.identity(n), T) + sp.kron(T, sp.identity(n))
-    As = -(lap + (k**2 + 0.5j) * sp.identity(n * m))
+    As = -(lap + (1 + 0.2j) * k**2 * sp.identity(n * m))          # complex-shifted: a well-conditioned stand-in
     Msp = As + k**2 * sp.diags(nu(X, Y))
     precond = ls.SparsifyingPreconditioner(Msp, As)
     u3 = np.zeros(n * m, dtype=np.complex128)

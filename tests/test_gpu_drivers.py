@@ -78,7 +78,9 @@ def test_example_2d_left_preconditioner_through_host_callback(lsfc, ex2d):
     rhs = ex2d.get("rhs")
     if rhs is None:
         rhs = -k ** 2 * lsfc.FFTconvolution(M, nu * np.exp(1j * k * X))
-    Msp, As = cases.sparsifying_pair_2d(n, h, k, nu)
+    # (complex-shifted stand-in, eps = 0.2 k^2: with the tiny shift of the unit tests the preconditioned operator is so
+    # ill-conditioned that 1e-16 apply differences grow to 1e-3 in the history within two restart cycles)
+    Msp, As = cases.sparsifying_pair_2d(n, h, k, nu, eps=0.2 * k ** 2)
     P = o.SparsifyingPreconditioner(Msp, As)                                 # host sparse LU (src/preconditioner.jl:35)
     calls = []
 
@@ -87,17 +89,17 @@ def test_example_2d_left_preconditioner_through_host_callback(lsfc, ex2d):
         P.ldiv_(v)                                                           # ldiv!(P, v), :147-170
 
     u = np.zeros(M.N, complex)
-    u, info = lsfc.gmres_(u, M, rhs, Pl=Pl, maxiter=40, log=True)
+    u, info = lsfc.gmres_(u, M, rhs, Pl=Pl, maxiter=60, log=True)
     assert len(calls) == info.mvps + 1
     uo = np.zeros(M.N, complex)
-    uo, ho = o.gmres(uo, A, rhs, Pl=P.solve, maxiter=40)
-    assert info.iters == ho.iters == 40 or (info.isconverged and ho.isconverged)
+    uo, ho = o.gmres(uo, A, rhs, Pl=P.solve, maxiter=60)
+    assert info.isconverged and ho.isconverged and abs(info.iters - ho.iters) <= 1
     _history_close(info["resnorm"], ho.resnorm, np.sqrt(np.finfo(float).eps), "example.jl:85 host callback")
     assert rel_err(u, uo) < 1e-6
     # the device-resident apply of the same preconditioner follows the same iterates
     Pd = lsfc.SparsifyingPreconditioner(Msp, As)
     ud = np.zeros(M.N, complex)
-    ud, infod = lsfc.gmres_(ud, M, rhs, Pl=Pd, maxiter=40, log=True)
+    ud, infod = lsfc.gmres_(ud, M, rhs, Pl=Pd, maxiter=60, log=True)
     _history_close(infod["resnorm"], ho.resnorm, np.sqrt(np.finfo(float).eps), "example.jl:85 device preconditioner")
     assert rel_err(ud, uo) < 1e-6
 
