@@ -235,6 +235,34 @@ template <class C, int S> __device__ __forceinline__ int stage_pos(int t, int e)
     return (b / M) * LS + (b % M) + M * q;
 }
 
+// Which thread (of the line) owns position `pos` in stage S, and the host/compile-time twin of stage_pos.
+template <class C, int S> constexpr int stage_owner(int pos) {
+    constexpr int LS = C::template LS<S>(), R = C::template R<S>();
+    constexpr int M = LS / R;
+    const int b = (pos / LS) * M + (pos % LS) % M;
+    return b % C::T;
+}
+template <class C, int S> constexpr int stage_pos_c(int t, int e) {
+    constexpr int LS = C::template LS<S>(), R = C::template R<S>();
+    constexpr int M = LS / R, NB = C::E / R;
+    const int u = e % NB, q = e / NB;
+    const int b = t + C::T * u;
+    return (b / M) * LS + (b % M) + M * q;
+}
+// An exchange SA -> SB is WAVE-LOCAL when every element stays among the threads t of one group of G consecutive t
+// (G = the threads of a line that share a wavefront: 64 / LINES for interleaved lines, min(T, 64) for contiguous
+// ones).  Such an exchange needs no workgroup barrier: LDS executes one wave's instructions in order, and no other
+// wave touches the positions involved -- the waves of a workgroup then drift apart and overlap each other's LDS and
+// VALU phases instead of marching in lock step.  (Cfg1024 = 16.8.8 with 8 interleaved lines: the exchange between the
+// two radix-8 stages moves data inside blocks of 64 positions owned by the 8 threads t = 8w .. 8w+7 of wave w.)
+template <class C, int SA, int SB> constexpr bool exchange_wave_local(int G) {
+    if (G >= C::T) return true;
+    for (int t = 0; t < C::T; ++t)
+        for (int e = 0; e < C::E; ++e)
+            if (stage_owner<C, SB>(stage_pos_c<C, SA>(t, e)) / G != t / G) return false;
+    return true;
+}
+
 // How the lines of one workgroup share LDS: address(pos) = off + (pos + pos>>PADSHIFT)*LSTR + xi
 template <int LSTR_, int PADSHIFT_, bool SPLIT_> struct LdsLayout {
     static constexpr int LSTR = LSTR_, PADSHIFT = PADSHIFT_;
@@ -243,6 +271,8 @@ template <int LSTR_, int PADSHIFT_, bool SPLIT_> struct LdsLayout {
     // elements (of 8 or 16 bytes) needed per line
     static constexpr int line_elems(int L) { return L + (L >> PADSHIFT); }
     static constexpr int elem_bytes() { return SPLIT ? 8 : 16; }
+    // threads t of one line that share a wavefront (lane = xi + LSTR * t for interleaved lines, t + T * line otherwise)
+    static constexpr int wave_group() { return LSTR == 1 ? 64 : (64 % LSTR == 0 ? 64 / LSTR : 1); }
 };
 
 // COMP: 0 = real parts, 1 = imaginary parts (SPLIT layouts), 2 = whole complex numbers
@@ -267,19 +297,49 @@ __device__ __forceinline__ void lds_read(cplx (&v)[C::E], int t, const char* sme
 }
 
 #ifndef LSFC_FFT_HOST_EMULATION
-template <class LL> __device__ __forceinline__ void lds_barrier() { LSFC_BARRIER(); }
+// Compile-time switch of the wave-local form: bit 0 contiguous (x) passes, bit 1 interleaved (y, z) passes.  DEFAULT 0 (every
+// exchange synchronises the whole workgroup): measured on MI355X the wave-local form changes nothing at 512^3 (fused
+// pass 6.05 -> 6.2 ms, x / y passes equal) and gains ~5 % on the fused pass at 256^3 only, and two of five test runs of
+// builds with bit 1 set ended in a GPU memory fault in the first apply of the session that no workgroup-barrier build
+// ever showed (profiles/r02_experiment_wave_local_sync.log).  Kept for the record and for A/B builds (make EXTRA=-DLSFC_WAVE_LOCAL_SYNC=1).
+#ifndef LSFC_WAVE_LOCAL_SYNC
+#define LSFC_WAVE_LOCAL_SYNC 0
+#endif
+// LOCAL: the exchange stays inside each wavefront -- order the wave's own LDS accesses, nothing else
+template <bool LOCAL> __device__ __forceinline__ void lds_barrier() {
+    if constexpr (LOCAL) {
+        // the wave drains its own LDS queue between the phases (s_waitcnt lgkmcnt(0): LDS only, global loads stay in flight)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else LSFC_BARRIER();
+}
+template <class C, int SA, int SB, class LL> constexpr bool exchange_is_local() {
+    constexpr int bit = LL::LSTR == 1 ? 1 : 2;
+    if constexpr ((LSFC_WAVE_LOCAL_SYNC & bit) == 0) return false;
+    else return exchange_wave_local<C, SA, SB>(LL::wave_group()) && exchange_wave_local<C, SB, SA>(LL::wave_group());
+}
 // Move every element from its stage-SA owner to its stage-SB owner through LDS.
 template <class C, int SA, int SB, class LL>
 __device__ __forceinline__ void exchange(cplx (&v)[C::E], int t, char* smem, int off, int xi) {
+    constexpr bool LOC = exchange_is_local<C, SA, SB, LL>();
     if constexpr (LL::SPLIT) {
-        lds_write<C, SA, LL, 0>(v, t, smem, off, xi); lds_barrier<LL>();
-        lds_read<C, SB, LL, 0>(v, t, smem, off, xi);  lds_barrier<LL>();
-        lds_write<C, SA, LL, 1>(v, t, smem, off, xi); lds_barrier<LL>();
-        lds_read<C, SB, LL, 1>(v, t, smem, off, xi);  lds_barrier<LL>();
+        lds_write<C, SA, LL, 0>(v, t, smem, off, xi); lds_barrier<LOC>();
+        lds_read<C, SB, LL, 0>(v, t, smem, off, xi);  lds_barrier<LOC>();
+        lds_write<C, SA, LL, 1>(v, t, smem, off, xi); lds_barrier<LOC>();
+        lds_read<C, SB, LL, 1>(v, t, smem, off, xi);  lds_barrier<LOC>();
     } else {
-        lds_write<C, SA, LL, 2>(v, t, smem, off, xi); lds_barrier<LL>();
-        lds_read<C, SB, LL, 2>(v, t, smem, off, xi);  lds_barrier<LL>();
+        lds_write<C, SA, LL, 2>(v, t, smem, off, xi); lds_barrier<LOC>();
+        lds_read<C, SB, LL, 2>(v, t, smem, off, xi);  lds_barrier<LOC>();
     }
+}
+// whether the forward transform ENDS with a wave-local exchange (callers that re-use the exchange buffer right after
+// it, as the fused pass does for the symbol, then need a workgroup barrier of their own)
+template <class C, class LL> constexpr bool forward_ends_local() {
+    if constexpr (C::NS >= 4) return exchange_is_local<C, 2, 3, LL>();
+    else if constexpr (C::NS >= 3) return exchange_is_local<C, 1, 2, LL>();
+    else return exchange_is_local<C, 0, 1, LL>();
 }
 #endif
 
@@ -296,20 +356,40 @@ __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __rest
         cplx a[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) a[q] = v[u + NB * q];
+        if constexpr (TWFULL && M > 1) {
+            // table twiddles: each is read and applied on the spot, four at a time (LSFC_TW_CHUNK), so that at most four
+            // of them are live instead of all R - 1 (60 registers at radix 16) -- what keeps the persistent fused pass,
+            // which also holds the next tile's data, inside the 256-register budget
+            const int r = (t + C::T * u) % M;
+            auto tw_at = [&](int q) { const cplx x = tw[C::template TWOFF<S>() + (q - 1) * M + r]; return (DIR < 0) ? cconj(x) : x; };
+            if constexpr (DIR < 0) {
+#pragma unroll
+                for (int q = 1; q < R; ++q) {
+                    a[q] = cmul(a[q], tw_at(q));
+#ifdef LSFC_TW_CHUNK
+                    if (q % LSFC_TW_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+            }
+            if constexpr (PRUNE == 1) dft_halfzero<R, DIR>(a);
+            else if constexpr (PRUNE == 2) dft_halfout<R, DIR>(a);
+            else Dft<R, DIR>::run(a);
+            if constexpr (DIR > 0) {
+#pragma unroll
+                for (int q = 1; q < R; ++q) {
+                    a[q] = cmul(a[q], tw_at(q));
+#ifdef LSFC_TW_CHUNK
+                    if (q % LSFC_TW_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+            }
+        } else {
         cplx w[R];
         if constexpr (M > 1) {
             const int r = (t + C::T * u) % M;
-            if constexpr (TWFULL) {
-#pragma unroll
-                for (int q = 1; q < R; ++q) {
-                    const cplx x = tw[C::template TWOFF<S>() + (q - 1) * M + r];
-                    w[q] = (DIR < 0) ? cconj(x) : x;
-                }
-            } else {
-                cplx w1 = tw[r * (C::L / LS)];
-                if constexpr (DIR < 0) w1 = cconj(w1);
-                twiddle_powers<R>(w1, w);
-            }
+            cplx w1 = tw[r * (C::L / LS)];
+            if constexpr (DIR < 0) w1 = cconj(w1);
+            twiddle_powers<R>(w1, w);
         }
         if constexpr (DIR < 0 && M > 1) {
 #pragma unroll
@@ -321,6 +401,7 @@ __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __rest
         if constexpr (DIR > 0 && M > 1) {
 #pragma unroll
             for (int q = 1; q < R; ++q) a[q] = cmul(a[q], w[q]);
+        }
         }
 #pragma unroll
         for (int q = 0; q < R; ++q) v[u + NB * q] = a[q];

@@ -244,6 +244,7 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
             fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
             if constexpr (ZE) {
                 cplx* stage = reinterpret_cast<cplx*>(smem);
+                if constexpr (forward_ends_local<C, LL>()) LSFC_BARRIER();   // other waves may still read the exchange buffer
 #pragma unroll
                 for (int e = 0; e < H; ++e) stage[(t + T * e) * LINES + li] = sv[e];
                 if (t == 0) stage[(C::L / 2) * LINES + li] = smid;
@@ -286,6 +287,7 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
         }
         // stage this line's stored half in LDS (the exchange buffer is free between the two transforms)
         cplx* stage = reinterpret_cast<cplx*>(smem);
+        if constexpr (forward_ends_local<C, LL>()) LSFC_BARRIER();   // other waves may still read the exchange buffer
 #pragma unroll
         for (int e = 0; e < H; ++e) stage[(t + T * e) * LINES + li] = sv[e];
         if (t == 0) stage[(C::L / 2) * LINES + li] = s[sLine * (C::L / 2)];
@@ -312,6 +314,111 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
     fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) if (EXACT || t + T * e < nin) d[dLine * (t + T * e)] = v[e];
+}
+
+// opaque copy of a value: the optimiser may not carry anything derived from the original across this point (used to keep
+// loop-invariant address arithmetic from being hoisted into registers that then live across the whole tile loop)
+template <class V> __device__ __forceinline__ V launder_v(V x) { asm volatile("" : "+v"(x)); return x; }
+template <class P> __device__ __forceinline__ P launder_s(P x) { asm volatile("" : "+s"(x)); return x; }
+
+// Persistent, software-pipelined form of the fused pass (z-even symbol, 8-line tiles of the 3D layout).
+// Why: with one workgroup per CU (the exchange buffer of a 1024-point tile fills the LDS) the plain kernel runs its
+// memory phases and its compute phases one after the other -- SQ counters at 512^3: waves parked 36 % of their life,
+// VALU active 21 %, and a CU cannot pull its 161 KB per tile faster than ~24 GB/s (6.7 us of the 11.2 us per tile).
+// Here one workgroup per CU walks over tiles b, b + G, b + 2G, ... and keeps the NEXT tile's data loads in flight under
+// the inverse transform of the current tile (they re-use the registers of the symbol values, which are dead after the
+// multiply), the symbol loads in flight under the forward transform as before, and the stores of the previous tile
+// drain under the next forward transform.  The stage-twiddle table and the mirror-slot table are set up once per
+// workgroup instead of once per tile.  Register pressure is that of the plain PREFETCH variant.
+template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL>
+__global__ __launch_bounds__(C::T * LINES, 1)
+void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
+                      int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
+                      const int2* __restrict__ ytab, const int* __restrict__ zm, int nin, unsigned ntiles) {
+    using LL = LdsLayout<LINES, 3, SPLIT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = C::T, E = C::E, H = E / 2;
+    const int xi = threadIdx.x % LINES, t = threadIdx.x / LINES, li = xi;
+    unsigned tile = blockIdx.x;
+    if (tile >= ntiles) return;                         // (uniform per workgroup; no inter-workgroup synchronisation anywhere)
+    if constexpr (TWL) {
+        cplx* tl = reinterpret_cast<cplx*>(smem + (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes());
+        for (int i = threadIdx.x; i < C::TWLEN; i += C::T * LINES) tl[i] = tw[i];
+        __syncthreads();
+        tw = tl;
+    }
+    // Addressing: a tile's base addresses are uniform (scalar registers), the thread's part is one 32-bit offset --
+    // 64-bit per-thread pointers kept across the loop cost the registers that decide between "fits" and "spills", and a
+    // spill reload at the loop top would make the wave wait for the previous tile's stores (scratch and global memory
+    // share the in-order vmcnt counter).
+    auto locate = [&](unsigned tl_, cplx*& dbase, const cplx*& sbase) {
+        const int o = (int)(tl_ % (unsigned)nouter), g = (int)(tl_ / (unsigned)nouter);
+        int outer = o, srow = o;
+        if (ytab) { const int2 e2 = ytab[o]; outer = e2.x; srow = e2.y; }
+        dbase = data + g * dGrp + outer * dOuter;
+        sbase = sym + g * sGrp + srow * sOuter;
+    };
+    // (unsigned: scalar base + zero-extended 32-bit lane offset is an addressing mode of the global instructions)
+    const unsigned doff = (unsigned)(xi + (int)dLine * t), dstep = (unsigned)((int)dLine * T);      // element j = t + T e of this thread's line
+    const unsigned soff = (unsigned)(xi + (int)sLine * t), sstep = (unsigned)((int)sLine * T);
+    cplx nd[H];                                        // data of the tile about to be transformed
+    {
+        cplx* d; const cplx* s;
+        locate(tile, d, s);
+#pragma unroll
+        for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? d[doff + dstep * e] : make_double2(0.0, 0.0);
+    }
+    for (;;) {
+        cplx sv[H];
+        cplx smid = make_double2(0.0, 0.0);
+        {
+            cplx* d; const cplx* s;
+            locate(tile, d, s);
+            const unsigned so = launder_v(soff);
+#pragma unroll
+            for (int e = 0; e < H; ++e) sv[e] = s[so + sstep * e];
+            if (t == 0) smid = s[so - (unsigned)((int)sLine * t) + (unsigned)((int)sLine * (C::L / 2))];
+        }
+        cplx v[E];
+#pragma unroll
+        for (int e = 0; e < H; ++e) { v[e] = nd[e]; v[e + H] = make_double2(0.0, 0.0); }
+        fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+        cplx* stage = reinterpret_cast<cplx*>(smem);
+        if constexpr (forward_ends_local<C, LL>()) LSFC_BARRIER();   // other waves may still read the exchange buffer
+#pragma unroll
+        for (int e = 0; e < H; ++e) stage[(t + T * e) * LINES + li] = sv[e];
+        if (t == 0) stage[(C::L / 2) * LINES + li] = smid;
+        LSFC_BARRIER();
+        {
+            const int* zmt = launder_s(zm) + t;            // (re-read per tile from L1: eight registers less across the loop)
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                v[e] = cmul(v[e], sv[e]);
+                v[e + H] = cmul(v[e + H], stage[zmt[T * e] * LINES + li]);
+            }
+        }
+        LSFC_BARRIER();
+        // next tile: its loads travel while this tile is transformed back
+        const unsigned next = tile + gridDim.x;
+        const bool more = next < ntiles;
+        if (more) {
+            cplx* dn; const cplx* sn;
+            locate(next, dn, sn);
+            const unsigned dof = launder_v(doff);
+#pragma unroll
+            for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? dn[dof + dstep * e] : make_double2(0.0, 0.0);
+        }
+        fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+        {
+            cplx* d; const cplx* s;
+            locate(tile, d, s);
+            const unsigned dof = launder_v(doff);
+#pragma unroll
+            for (int e = 0; e < H; ++e) if (EXACT || t + T * e < nin) d[dof + dstep * e] = v[e];
+        }
+        if (!more) break;
+        tile = next;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -411,6 +518,31 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
                            (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab, zm, nin, nrhs, dBatch);
     }
+}
+
+// persistent pipelined fused pass: z-even symbol, whole 8-line tiles (3D layout); one workgroup per CU
+template <class C, bool SPLIT> static void zfused_persist_t(cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
+                                                            int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
+                                                            const int2* ytab, const int* zm, int nin, hipStream_t st) {
+    constexpr int LINES = XB;
+    using LL = LdsLayout<LINES, 3, SPLIT>;
+    size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
+    if (twl && lds + (size_t)C::TWLEN * sizeof(cplx) > (size_t)160 * 1024) twl = nullptr;
+    auto k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false> : k_zfused_persist<C, LINES, SPLIT, false, false>;
+    if (twl) {
+        k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true> : k_zfused_persist<C, LINES, SPLIT, false, true>;
+        lds += (size_t)C::TWLEN * sizeof(cplx);
+        tw = twl;
+    }
+    allow_lds(k, lds);
+    static int cus = 0;
+    if (!cus) { int dev = 0; LSFC_HIP(hipGetDevice(&dev)); hipDeviceProp_t pr; LSFC_HIP(hipGetDeviceProperties(&pr, dev)); cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    const unsigned ntiles = (unsigned)((Lx / XB) * nouter);
+    // workgroups per CU that fit (LDS-limited); the walk stays interleaved so that co-resident workgroups touch neighbouring tiles
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)160 * 1024) / lds));
+    const unsigned grid = std::min<unsigned>(ntiles, (unsigned)(cus * per_cu));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
+                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, ntiles);
 }
 
 // half-tile z pass (L = 1024 and L = 1536 in the 3D tiled layout only): 4-line workgroups, sibling halves 8 blocks apart
@@ -514,6 +646,23 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
     const bool tiled = dLine == 8 && ((int64_t)(Lx / XB) * nouter) % 8 == 0;
     const bool half_form = (LSFC_FAMILY == 2 && ((L == 1024 && (tn.z_half >= 0 ? tn.z_half : (zm ? 0 : 2)) > 0 && tiled) || (L == 2048 && dLine == 8)))
                         || (LSFC_FAMILY == 3 && L == 1536 && (tn.z_half >= 0 ? tn.z_half : 1) > 0 && tiled);
+    // persistent pipelined form: z-even symbol, 3D tiled layout, whole 8-line tiles, one right-hand side
+    {
+        // auto: whole-complex exchanges below 1024 points; at 1024 points (16 elements per thread) the split form, the only
+        // one the compiler fits into 256 registers without scratch (5.45 against 5.85 ms at 512^3)
+        const int zp = tn.z_persist >= 0 ? tn.z_persist : (L >= 1024 ? 2 : 1);
+        bool eight_lines = false;
+        LSFC_DISPATCH_L(L, (eight_lines = Tune<C>::LINES == XB));
+        if (zp > 0 && zm && dLine == 8 && nrhs == 1 && eight_lines && !half_form) {
+            size_t full_lds = 0;
+            LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<XB, 3, false>::line_elems(C::L) * XB * 16));
+            const bool split = zp == 2 || full_lds > (size_t)160 * 1024;
+            if (split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
+            else       { LSFC_DISPATCH_L(L, (zfused_persist_t<C, false>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
+            LSFC_HIP(hipGetLastError());
+            return;
+        }
+    }
     if (nrhs > 1 && half_form) {
         for (int r = 0; r < nrhs; ++r)
             FAM(pruned_zfused)(L, tn, data + (int64_t)r * dBatch, sym, tw, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, 1, 0);

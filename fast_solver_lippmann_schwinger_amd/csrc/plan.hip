@@ -333,7 +333,9 @@ void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
 
 void plan_convolve_batch_dev(lsfc_plan* p, int nrhs, const VecBatch& vb, bool use_nu, double alpha, double beta) {
     LSFC_REQUIRE(nrhs >= 1 && nrhs <= LSFC_MAX_BATCH, "batch of %d right-hand sides (1..%d per pass)", nrhs, LSFC_MAX_BATCH);
-    if (nrhs == 1 || p->dist || p->multi || p->pipeline != lsfc_plan::PRUNED) {
+    const bool fuse = p->tuning.batch_fuse > 0 ||
+                      (p->tuning.batch_fuse < 0 && (int64_t)p->pads[0] * p->pads[1] * p->pads[2] <= ((int64_t)1 << 24));
+    if (nrhs == 1 || p->dist || p->multi || p->pipeline != lsfc_plan::PRUNED || !fuse) {
         for (int j = 0; j < nrhs; ++j) plan_convolve_dev(p, vb.x[j], vb.y[j], use_nu, alpha, beta);
         return;
     }
@@ -697,6 +699,8 @@ int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value) {
         else if (k == "sym_prefetch") plan->tuning.sym_prefetch = value;
         else if (k == "ytile_g") plan->tuning.ytile_g = value;
         else if (k == "ytile_z") plan->tuning.ytile_z = value;
+        else if (k == "batch_fuse") plan->tuning.batch_fuse = value;
+        else if (k == "z_persist") plan->tuning.z_persist = value;
         else fail(LSFC_EINVAL, "unknown tuning key '%s'", key);
     });
 }

@@ -1,6 +1,7 @@
 // Front end of the hand-written axis passes: routes every call to the family of its line length (fft_kernels.hip is
 // compiled once per family: power-of-two lines, lines with one factor 3, lines with one factor 5).
 #include "pruned.hpp"
+#include <cstdio>
 #include <cstdlib>
 
 namespace lsfc {
@@ -38,12 +39,22 @@ int pruned_best_length(int64_t n) {
     return 0;
 }
 
+// LSFC_DEBUG_SYNC=1 (developer switch): synchronise the device after every pass and name the pass that failed -- turns an
+// asynchronous GPU fault or launch error into an error message at the kernel that caused it
+static bool debug_sync() { static const bool on = getenv("LSFC_DEBUG_SYNC") && getenv("LSFC_DEBUG_SYNC")[0] == '1'; return on; }
+static void debug_check(const char* pass, int L) {
+    if (!debug_sync()) return;
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipGetLastError(); fail(LSFC_EHIP, "%s (line length %d) failed: %s", pass, L, hipGetErrorString(e)); }
+    fprintf(stderr, "[lsfc debug] %s L=%d ok\n", pass, L);
+}
 #define LSFC_ROUTE(L, NAME, ...)                                            \
     switch (family(L)) {                                                    \
     case 2: NAME##_f2(__VA_ARGS__); break;                                  \
     case 3: NAME##_f3(__VA_ARGS__); break;                                  \
     case 5: NAME##_f5(__VA_ARGS__); break;                                  \
-    default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); }
+    default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); } \
+    debug_check(#NAME, (int)(L));
 
 void pruned_xfwd(int L, const PrunedTuning& tn, const VecBatch& vb, int nrhs, int64_t obatch, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int W, int Wp, int n, hipStream_t st, int64_t bstride) {
     LSFC_REQUIRE(nrhs >= 1 && nrhs <= LSFC_MAX_BATCH, "batch of %d right-hand sides (1..%d per launch)", nrhs, LSFC_MAX_BATCH);
@@ -64,7 +75,13 @@ void pruned_zfused(int L, const PrunedTuning& tn, cplx* data, const cplx* sym, c
                    const int* zm, int nin, hipStream_t st, int nrhs, int64_t dBatch) {
     LSFC_ROUTE(L, pruned_zfused, L, tn, data, sym, tw, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, nrhs, dBatch);
 }
-void pruned_perm(int L, int* freq_of_storage) { LSFC_ROUTE(L, pruned_perm, L, freq_of_storage); }
+void pruned_perm(int L, int* freq_of_storage) {
+    switch (family(L)) {
+    case 2: pruned_perm_f2(L, freq_of_storage); break;
+    case 3: pruned_perm_f3(L, freq_of_storage); break;
+    case 5: pruned_perm_f5(L, freq_of_storage); break;
+    default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", L); }
+}
 int pruned_twfull_len(int L) {
     switch (family(L)) {
     case 2: return pruned_twfull_len_f2(L);
@@ -73,7 +90,13 @@ int pruned_twfull_len(int L) {
     default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", L);
     }
 }
-void pruned_twfull(int L, const cplx* tw, cplx* out) { LSFC_ROUTE(L, pruned_twfull, L, tw, out); }
+void pruned_twfull(int L, const cplx* tw, cplx* out) {
+    switch (family(L)) {
+    case 2: pruned_twfull_f2(L, tw, out); break;
+    case 3: pruned_twfull_f3(L, tw, out); break;
+    case 5: pruned_twfull_f5(L, tw, out); break;
+    default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", L); }
+}
 
 static bool env_flag(const char* name, bool dflt) {
     const char* v = getenv(name);
@@ -93,6 +116,8 @@ PrunedTuning pruned_default_tuning() {
     if (const char* v = getenv("LSFC_SYM_PREFETCH")) t.sym_prefetch = atoi(v);
     if (const char* v = getenv("LSFC_YTILE_G")) t.ytile_g = atoi(v);
     if (const char* v = getenv("LSFC_YTILE_Z")) t.ytile_z = atoi(v);
+    if (const char* v = getenv("LSFC_BATCH_FUSE")) t.batch_fuse = atoi(v);
+    if (const char* v = getenv("LSFC_Z_PERSIST")) t.z_persist = atoi(v);
     return t;
 }
 

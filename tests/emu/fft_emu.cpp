@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include <complex>
+#include <cstring>
 struct double2 { double x, y; };
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 #define __device__
@@ -18,6 +19,7 @@ static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 
 using namespace lsfc::fft;
 typedef std::complex<long double> lc;
+static long g_local_exchanges = 0;      // exchanges emulated wave group by wave group
 
 template <class C, class LL, int SA, int SB>
 static void emu_exchange(std::vector<std::vector<cplx>>& regs, std::vector<char>& smem, int nlines, int LSTRmode) {
@@ -26,18 +28,28 @@ static void emu_exchange(std::vector<std::vector<cplx>>& regs, std::vector<char>
         if (LL::LSTR == 1) { off = line * LL::line_elems(C::L); xi = 0; } else { off = 0; xi = line; }
     };
     const int comps = LL::SPLIT ? 2 : 1;
+    // An exchange the kernels treat as WAVE-LOCAL (fft_core.hpp: exchange_wave_local) is emulated the way the device
+    // runs it: wave group by wave group, each group writing and immediately reading with every other group's data
+    // absent (the buffer is poisoned first).  If the locality claim were wrong the reads would pick up poison and the
+    // comparison with the naive DFT would fail.  Other exchanges: all writes, (barrier), all reads.
+    const bool local = exchange_wave_local<C, SA, SB>(LL::wave_group()) && exchange_wave_local<C, SB, SA>(LL::wave_group());
+    const int G = local ? (LL::wave_group() < C::T ? LL::wave_group() : C::T) : C::T;
+    g_local_exchanges += local ? 1 : 0;
     for (int c = 0; c < comps; ++c) {
-        for (int line = 0; line < nlines; ++line) for (int t = 0; t < C::T; ++t) {
-            int off, xi; offxi(line, off, xi);
-            cplx (&v)[C::E] = *reinterpret_cast<cplx(*)[C::E]>(regs[line * C::T + t].data());
-            if (LL::SPLIT) { if (c == 0) lds_write<C, SA, LL, 0>(v, t, smem.data(), off, xi); else lds_write<C, SA, LL, 1>(v, t, smem.data(), off, xi); }
-            else lds_write<C, SA, LL, 2>(v, t, smem.data(), off, xi);
-        }
-        for (int line = 0; line < nlines; ++line) for (int t = 0; t < C::T; ++t) {
-            int off, xi; offxi(line, off, xi);
-            cplx (&v)[C::E] = *reinterpret_cast<cplx(*)[C::E]>(regs[line * C::T + t].data());
-            if (LL::SPLIT) { if (c == 0) lds_read<C, SB, LL, 0>(v, t, smem.data(), off, xi); else lds_read<C, SB, LL, 1>(v, t, smem.data(), off, xi); }
-            else lds_read<C, SB, LL, 2>(v, t, smem.data(), off, xi);
+        for (size_t i = 0; i + sizeof(double) <= smem.size(); i += sizeof(double)) { const double nan = NAN; memcpy(&smem[i], &nan, sizeof nan); }
+        for (int g0 = 0; g0 < C::T; g0 += G) {
+            for (int line = 0; line < nlines; ++line) for (int t = g0; t < g0 + G; ++t) {
+                int off, xi; offxi(line, off, xi);
+                cplx (&v)[C::E] = *reinterpret_cast<cplx(*)[C::E]>(regs[line * C::T + t].data());
+                if (LL::SPLIT) { if (c == 0) lds_write<C, SA, LL, 0>(v, t, smem.data(), off, xi); else lds_write<C, SA, LL, 1>(v, t, smem.data(), off, xi); }
+                else lds_write<C, SA, LL, 2>(v, t, smem.data(), off, xi);
+            }
+            for (int line = 0; line < nlines; ++line) for (int t = g0; t < g0 + G; ++t) {
+                int off, xi; offxi(line, off, xi);
+                cplx (&v)[C::E] = *reinterpret_cast<cplx(*)[C::E]>(regs[line * C::T + t].data());
+                if (LL::SPLIT) { if (c == 0) lds_read<C, SB, LL, 0>(v, t, smem.data(), off, xi); else lds_read<C, SB, LL, 1>(v, t, smem.data(), off, xi); }
+                else lds_read<C, SB, LL, 2>(v, t, smem.data(), off, xi);
+            }
         }
     }
 }
@@ -118,6 +130,10 @@ int main() {
     RUN(Cfg48); RUN(Cfg96); RUN(Cfg192); RUN(Cfg384); RUN(Cfg768); RUN(Cfg1536);
     RUN(Cfg80); RUN(Cfg160); RUN(Cfg320); RUN(Cfg640); RUN(Cfg1280);
     }
+    // the 1024-point line in 8 interleaved lines (the z pass at 512^3) must have its radix-8 <-> radix-8 exchange local
+    static_assert(exchange_wave_local<Cfg1024, 1, 2>(8) && exchange_wave_local<Cfg1024, 2, 1>(8) && !exchange_wave_local<Cfg1024, 0, 1>(8), "Cfg1024 locality");
+    static_assert(exchange_wave_local<Cfg1024, 0, 1>(64) && exchange_wave_local<Cfg512, 0, 1>(64), "one wave per contiguous line");
+    printf("wave-local exchanges emulated group by group: %ld\n", g_local_exchanges);
     printf("worst=%.3e\n", worst);
     return worst < 1e-13 ? 0 : 1;
 }

@@ -72,6 +72,7 @@ def test_apply_batch_n128_device_resident_and_interleaved_with_single_applies(ls
     g = np.exp(-40 * x ** 2)
     nu = (0.3 * g[:, None, None] * g[None, :, None] * g[None, None, :]).reshape(-1)
     M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, k, nu)
+    M.set_tuning(batch_fuse=1)
     G2 = o.reduced_symbol_gv3d(n, n, n, 1.0, k, patch_singular=False)
     B = _columns(n ** 3, 3)
     Bd = torch.from_numpy(B).cuda()

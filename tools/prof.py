@@ -11,11 +11,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fast_solver_lippmann_schwinger_amd as lsfc  # noqa: E402
 
 PEAK = 8.0e12
-BASE = dict(split_x=1, split_s=1, split_z=-1, sym_prefetch=-1, ytile_g=0, ytile_z=0, z_half=-1, tw_lds=1)
+BASE = dict(split_x=1, split_s=1, split_z=-1, sym_prefetch=-1, ytile_g=0, ytile_z=0, z_half=-1, tw_lds=1, z_persist=-1)
 
-VARIANTS = [("auto", {}, {}),
-            ("no symmetry, no padding, first-version launch order", {"LSFC_SYM_EVEN_Y": "0", "LSFC_SYM_EVEN_Z": "0", "LSFC_PAD1": "0", "LSFC_PAD2": "0"},
-             dict(split_z=1, sym_prefetch=0, ytile_g=4096, ytile_z=1, z_half=0, tw_lds=0))]
+VARIANTS = [("auto (persistent pipelined z pass)", {}, {}),
+            ("one tile per workgroup (round 1)", {}, dict(z_persist=0)),
+            ("persistent, whole-complex exchanges", {}, dict(z_persist=1)),
+            ("persistent, split exchanges", {}, dict(z_persist=2))]
 
 
 def run(n, reps=5):
