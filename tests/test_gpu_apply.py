@@ -382,7 +382,8 @@ def test_error_paths_and_edge_cases(lsfc):
 
 
 def test_c_api_example_compiles_and_runs(lsfc, tmp_path):
-    # the boundary is usable from plain C: examples/c_api_example.c built with gcc against liblsfc.so
+    # the boundary is usable from plain C: examples/c_api_example.c built with gcc against liblsfc.so.  The child process
+    # loads the system ROCm stack only (no torch): single-GPU solve, multi-device plan, slab plan over RCCL of /opt/rocm
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     libdir = os.path.join(root, "fast_solver_lippmann_schwinger_amd")
@@ -392,4 +393,4 @@ def test_c_api_example_compiles_and_runs(lsfc, tmp_path):
     assert r.returncode == 0, r.stderr.decode()
     r = subprocess.run([exe, "32"], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
-    assert b"converged=1" in r.stdout
+    assert b"converged=1" in r.stdout and b"multi-device plan on" in r.stdout and b"RCCL send/recv self exchange" in r.stdout
