@@ -330,7 +330,7 @@ template <class P> __device__ __forceinline__ P launder_s(P x) { asm volatile(""
 // multiply), the symbol loads in flight under the forward transform as before, and the stores of the previous tile
 // drain under the next forward transform.  The stage-twiddle table and the mirror-slot table are set up once per
 // workgroup instead of once per tile.  Register pressure is that of the plain PREFETCH variant.
-template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL>
+template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL, bool LATE_SYM = false>
 __global__ __launch_bounds__(C::T * LINES, 1)
 void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
                       int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
@@ -369,20 +369,31 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? d[doff + dstep * e] : make_double2(0.0, 0.0);
     }
     for (;;) {
+        cplx v[E];
+#pragma unroll
+        for (int e = 0; e < H; ++e) { v[e] = nd[e]; v[e + H] = make_double2(0.0, 0.0); }
         cplx sv[H];
         cplx smid = make_double2(0.0, 0.0);
-        {
+        auto load_symbol = [&] {
             cplx* d; const cplx* s;
             locate(tile, d, s);
             const unsigned so = launder_v(soff);
 #pragma unroll
             for (int e = 0; e < H; ++e) sv[e] = s[so + sstep * e];
             if (t == 0) smid = s[so - (unsigned)((int)sLine * t) + (unsigned)((int)sLine * (C::L / 2))];
+        };
+        if constexpr (LATE_SYM) {
+            // the first forward stage (the widest butterfly plus its twiddles) runs before the symbol values occupy registers
+            stage<C, 0, +1, 1, TWL>(v, t, tw);
+            load_symbol();
+            exchange<C, 0, 1, LL>(v, t, smem, 0, li);
+            stage<C, 1, +1, 0, TWL>(v, t, tw);
+            if constexpr (C::NS >= 3) { exchange<C, 1, 2, LL>(v, t, smem, 0, li); stage<C, 2, +1, 0, TWL>(v, t, tw); }
+            if constexpr (C::NS >= 4) { exchange<C, 2, 3, LL>(v, t, smem, 0, li); stage<C, 3, +1, 0, TWL>(v, t, tw); }
+        } else {
+            load_symbol();
+            fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         }
-        cplx v[E];
-#pragma unroll
-        for (int e = 0; e < H; ++e) { v[e] = nd[e]; v[e + H] = make_double2(0.0, 0.0); }
-        fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         cplx* stage = reinterpret_cast<cplx*>(smem);
         if constexpr (forward_ends_local<C, LL>()) LSFC_BARRIER();   // other waves may still read the exchange buffer
 #pragma unroll
@@ -521,16 +532,16 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
 }
 
 // persistent pipelined fused pass: z-even symbol, whole 8-line tiles (3D layout); one workgroup per CU
-template <class C, bool SPLIT> static void zfused_persist_t(cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
+template <class C, bool SPLIT, bool LATE_SYM = false> static void zfused_persist_t(cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                                                             int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
                                                             const int2* ytab, const int* zm, int nin, hipStream_t st) {
     constexpr int LINES = XB;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     if (twl && lds + (size_t)C::TWLEN * sizeof(cplx) > (size_t)160 * 1024) twl = nullptr;
-    auto k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false> : k_zfused_persist<C, LINES, SPLIT, false, false>;
+    auto k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false, LATE_SYM> : k_zfused_persist<C, LINES, SPLIT, false, false, LATE_SYM>;
     if (twl) {
-        k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true> : k_zfused_persist<C, LINES, SPLIT, false, true>;
+        k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM>;
         lds += (size_t)C::TWLEN * sizeof(cplx);
         tw = twl;
     }
@@ -648,9 +659,10 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
                         || (LSFC_FAMILY == 3 && L == 1536 && (tn.z_half >= 0 ? tn.z_half : 1) > 0 && tiled);
     // persistent pipelined form: z-even symbol, 3D tiled layout, whole 8-line tiles, one right-hand side
     {
-        // auto: whole-complex exchanges below 1024 points; at 1024 points (16 elements per thread) the split form, the only
-        // one the compiler fits into 256 registers without scratch (5.45 against 5.85 ms at 512^3)
-        const int zp = tn.z_persist >= 0 ? tn.z_persist : (L >= 1024 ? 2 : 1);
+        // z_persist: 1 whole-complex exchanges, 2 split exchanges, 3 / 4 the same with the symbol loaded after the first forward
+        // stage (its 32 registers stay free during the widest butterfly); auto = 3: 5.24 ms at 512^3 against 5.73 for the
+        // one-tile kernel, 0.58 against 0.675 ms at 256^3 (profiles/r02_experiment_persistent_zpass.log)
+        const int zp = tn.z_persist >= 0 ? tn.z_persist : 3;
         bool eight_lines = false;
         LSFC_DISPATCH_L(L, (eight_lines = Tune<C>::LINES == XB));
         // (worth it only when a workgroup walks over several tiles: below ~4 tiles per resident workgroup -- grids up to 64^3 --
@@ -659,8 +671,10 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
         if (zp > 0 && zm && dLine == 8 && nrhs == 1 && eight_lines && !half_form && enough_tiles) {
             size_t full_lds = 0;
             LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<XB, 3, false>::line_elems(C::L) * XB * 16));
-            const bool split = zp == 2 || full_lds > (size_t)160 * 1024;
-            if (split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
+            const bool split = zp == 2 || zp == 4 || full_lds > (size_t)160 * 1024;
+            if (zp == 3 && !split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
+            else if (zp >= 3) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
+            else if (split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
             else       { LSFC_DISPATCH_L(L, (zfused_persist_t<C, false>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
             LSFC_HIP(hipGetLastError());
             return;

@@ -22,8 +22,9 @@ struct PrunedTuning {
     int tw_lds = 1;                 // fused pass (full-tile form): stage twiddles from an LDS-resident table instead of product
                                     // trees (-2..3 % on the pass, exact twiddles; profiles/r01_experiment_lds_twiddle_table.log)
     int z_half = -1;                // L = 1024 z pass: half-tile 4-wave workgroups (0 off, 1: full+prefetch, 2: split+prefetch, 3: split 3 WG/CU, 4: full; -1 auto)
-    int z_persist = -1;             // fused pass with a z-even symbol in the 3D layout: 1 persistent software-pipelined kernel (auto),
-                                    // 2 the same with split exchanges, 0 the one-tile-per-workgroup kernels
+    int z_persist = -1;             // fused pass with a z-even symbol in the 3D layout: persistent software-pipelined kernel -- 1 whole-complex
+                                    // exchanges, 2 split exchanges, 3 (auto) / 4 the same with the symbol loaded after the first forward
+                                    // stage; 0 the one-tile-per-workgroup kernels
     int ytile_g = 0, ytile_z = 0;   // y passes: block-order tile (x'-groups x z planes); 0 = auto
     int batch_fuse = -1;            // several right-hand sides: 1 one fused pass per group, 0 member by member, -1 auto (fused while
                                     // the padded grid has <= 2^24 points, where launches and not bytes bound the apply:

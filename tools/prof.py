@@ -16,7 +16,9 @@ BASE = dict(split_x=1, split_s=1, split_z=-1, sym_prefetch=-1, ytile_g=0, ytile_
 VARIANTS = [("auto (persistent pipelined z pass)", {}, {}),
             ("one tile per workgroup (round 1)", {}, dict(z_persist=0)),
             ("persistent, whole-complex exchanges", {}, dict(z_persist=1)),
-            ("persistent, split exchanges", {}, dict(z_persist=2))]
+            ("persistent, split exchanges", {}, dict(z_persist=2)),
+            ("persistent, whole, symbol after stage 0", {}, dict(z_persist=3)),
+            ("persistent, split, symbol after stage 0", {}, dict(z_persist=4))]
 
 
 def run(n, reps=5):
