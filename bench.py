@@ -150,7 +150,7 @@ def cpu_baseline(n_target, nu, xvec):
             "measured_s_per_apply_sample": best, "all_sample_s": times, "sample_n": n}
 
 
-def parity_gate(lsfc, sizes, rank, world, local_rank, dist):
+def parity_gate(lsfc, sizes, rank, world, local_rank, dist, multi_devices=None):
     """the bench's (nu, omega = 1/h) recipe at small n on THIS build and device(s) vs the CPU oracle"""
     from oracle import lsfc_oracle as o
     worst = {}
@@ -160,7 +160,10 @@ def parity_gate(lsfc, sizes, rank, world, local_rank, dist):
         lo, hi = rank * n // world, (rank + 1) * n // world
         b = bench_vector(n, 0, n)
         nu = synthetic_nu(n, 0, n)
-        if world == 1:
+        if multi_devices is not None:
+            from fast_solver_lippmann_schwinger_amd.distributed import MultiDeviceFastM3D
+            M = MultiDeviceFastM3D(n, h, omega, nu, devices=multi_devices)
+        elif world == 1:
             xg = -0.5 + h * np.arange(n)
             M = lsfc.buildFastConvolution3D(xg, xg, xg, None, None, None, h, omega, nu, device=local_rank)
         else:
@@ -192,6 +195,8 @@ def main():
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the oracle check (profiling runs only; the line then says so)")
     ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (rehearsal of the multi-GPU path)")
     ap.add_argument("--single-process", action="store_true", help="drive all --gpus devices from this one process (multi-device plan)")
+    ap.add_argument("--devices", type=str, default="", help="with --single-process: comma-separated device ids, one per rank; a device may repeat "
+                    "(logical ranks on one GPU, peer-copy transport): a rehearsal of the path where fewer GPUs are visible, not a measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -218,15 +223,21 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     parity = None
-    if not args.no_parity_gate and not args.single_process:
-        parity = parity_gate(lsfc, [64, 128] if world == 1 else [64], rank, world, local_rank, dist if world > 1 else None)
+    multi_devs = None
+    if args.single_process and args.gpus > 1:
+        multi_devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        if len(multi_devs) != args.gpus:
+            raise SystemExit(f"--devices lists {len(multi_devs)} ids for --gpus {args.gpus}")
+    if not args.no_parity_gate:
+        parity = parity_gate(lsfc, [64, 128] if (world == 1 and multi_devs is None) else [64], rank, world, local_rank,
+                             dist if world > 1 else None, multi_devs)
 
     nu_host = None
     multi = None
     if args.single_process and args.gpus > 1:
         from fast_solver_lippmann_schwinger_amd.distributed import MultiDeviceFastM3D
         nu_host = synthetic_nu(n, 0, n)
-        multi = MultiDeviceFastM3D(n, h, omega, nu_host, devices=list(range(args.gpus)))
+        multi = MultiDeviceFastM3D(n, h, omega, nu_host, devices=multi_devs)
         world_eff = args.gpus
     elif world == 1 and not args.force_dist:
         nu_host = synthetic_nu(n, 0, n)
@@ -314,10 +325,11 @@ def main():
                                   f"omega=1/h={omega:g}, sum-of-8-Gaussians contrast, vectors resident in HBM",
                       "n": n, "omega": omega, "pipeline": pipeline, "padded_grid": padded,
                       "parallelism": "single GPU" if world_eff == 1 else
-                                     (f"z-slabs over {world_eff} GPUs, 2 all-to-all slab transposes per apply, "
-                                      + ("ONE host process driving all devices" if multi is not None else "one process per GPU, RCCL send/recv"))},
+                                     (f"z-slabs over {world_eff} ranks, 2 all-to-all slab transposes per apply, "
+                                      + ((f"ONE host process driving devices {multi.devices}" + (" -- REHEARSAL: ranks share a GPU, not a multi-GPU measurement" if len(set(multi.devices)) < len(multi.devices) else ""))
+                                         if multi is not None else "one process per GPU, RCCL send/recv"))},
            "achieved_algorithmic_GBps_per_gpu": whole / world_eff, "hbm_roofline_frac_whole_apply": whole / world_eff / HBM_PEAK_GBPS,
-           "parity_rel_l2": parity if parity is not None else "gate skipped (--no-parity-gate / --single-process)",
+           "parity_rel_l2": parity if parity is not None else "gate skipped (--no-parity-gate)",
            "parity_tol": PARITY_TOL,
            "roofline": roofline}
     if world_eff > 1:

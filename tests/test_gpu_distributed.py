@@ -204,3 +204,20 @@ def test_multi_device_plan_argument_errors(lsfc):
         MultiDeviceFastM3D(32, 1 / 32, 5.0, nu, devices=[0, 0, 0])          # 3 ranks: not a power of two dividing l
     with pytest.raises(lsfc.LsfcError):
         MultiDeviceFastM3D(32, 1 / 32, 5.0, nu, devices=[0, 99])            # no such device
+
+
+def test_bench_single_process_rehearsal(lsfc):
+    # bench.py --single-process with two logical ranks on device 0 (peer-copy transport): the N > 1 line carries the
+    # exchange object and says that it is a rehearsal
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process", "--devices", "0,0", "--n", "64",
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "REHEARSAL" in line["config"]["parallelism"]
+    assert set(line["exchange"]["unoverlapped_ms"]) == {"alltoall_in", "alltoall_back"} and "copies" in line["exchange"]["transport"]
+    assert line["value"] > 0 and line["roofline"]["kernel"] in ("zfused", "yfwd", "yinv", "xfwd", "xinv")
