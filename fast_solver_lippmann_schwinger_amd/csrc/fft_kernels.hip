@@ -603,6 +603,15 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     default: fail(LSFC_EINVAL, "pruned pipeline: unsupported padded length %d", (int)(L)); }
 #endif
 
+// Loads this family's code object (several MB: hundreds of kernel instantiations) on the current device.  HIP loads code
+// objects lazily at the first launch from them; done here, once per device at plan creation and followed by a device
+// synchronisation, the load never runs concurrently with a caller's transfers or the first real pass.
+__global__ void FAM(k_warmup)(int* p) { if (p) *p = 0; }
+void FAM(pruned_warmup)() {
+    hipLaunchKernelGGL(FAM(k_warmup), dim3(1), dim3(64), 0, 0, (int*)nullptr);
+    LSFC_HIP(hipGetLastError());
+}
+
 void FAM(pruned_perm)(int L, int* freq_of_storage) {
     LSFC_DISPATCH_L(L, perm_table<C>(freq_of_storage));
 }

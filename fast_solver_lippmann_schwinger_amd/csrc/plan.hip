@@ -91,6 +91,7 @@ void plan_common_init(lsfc_plan* p, int ndim, int64_t n, int64_t m, int64_t l, c
                  "unknown quadRule %d (the reference leaves B undefined, src/FastConvolution.jl:106)", quad_rule);
     LSFC_REQUIRE(nu_host != nullptr, "nu is NULL");
     select_device(device);
+    pruned_warmup(device);
     p->device = device; p->ndim = ndim;
     p->dims[0] = (int)n; p->dims[1] = (int)m; p->dims[2] = (int)l;
     p->N = n * m * l; p->omega = omega; p->quad_rule = quad_rule; p->flags = flags;
@@ -394,7 +395,14 @@ static void convolve_any(lsfc_plan* p, const double* x, double* y, int64_t nrhs,
     ensure_staging(p, p->N * group);
     for (int64_t j0 = 0; j0 < nrhs; j0 += group) {
         const int cnt = (int)std::min<int64_t>(group, nrhs - j0);
-        LSFC_HIP(hipMemcpyAsync(p->xs.p, (const cplx*)x + j0 * p->N, (size_t)cnt * p->N * sizeof(cplx), hipMemcpyHostToDevice, p->stream));
+        // (synchronous copy of the caller's pageable vector: round 2 saw an intermittent GPU memory fault in the very first
+        // host-vector apply of a process -- first kernel behind an asynchronous copy from pageable memory, garbage fault
+        // address far from every buffer of the plan; the host path is PCIe-bound either way)
+        LSFC_HIP(hipStreamSynchronize(p->stream));
+        LSFC_HIP(hipMemcpy(p->xs.p, (const cplx*)x + j0 * p->N, (size_t)cnt * p->N * sizeof(cplx), hipMemcpyHostToDevice));
+        if (getenv("LSFC_DEBUG_SYNC") && getenv("LSFC_DEBUG_SYNC")[0] == '1')
+            fprintf(stderr, "[lsfc debug] h2d of %lld bytes from %p to %p done; nu %p A1 %p (%zu B) tw0 %p sym %p (%zu B) ys %p\n", (long long)(cnt * p->N * sizeof(cplx)),
+                    (const void*)x, (void*)p->xs.p, (void*)p->nu.p, (void*)p->A1.p, p->A1.bytes(), (void*)p->tw[0].p, (void*)p->sym.p, p->sym.bytes(), (void*)p->ys.p);
         VecBatch vb{};
         for (int j = 0; j < cnt; ++j) { vb.x[j] = p->xs.p + (int64_t)j * p->N; vb.y[j] = p->ys.p + (int64_t)j * p->N; }
         plan_convolve_batch_dev(p, cnt, vb, use_nu, alpha, beta);

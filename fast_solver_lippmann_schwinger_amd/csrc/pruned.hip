@@ -3,6 +3,8 @@
 #include "pruned.hpp"
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 
 namespace lsfc {
 
@@ -13,7 +15,8 @@ namespace lsfc {
     void pruned_yinv_f##F(int, const PrunedTuning&, const cplx*, cplx*, const cplx*, int, int, int, int, int, hipStream_t, int, int64_t, int64_t);     \
     void pruned_zfused_f##F(int, const PrunedTuning&, cplx*, const cplx*, const cplx*, const cplx*, int, int, int64_t, int64_t, int64_t, \
                             int64_t, int64_t, int64_t, const int2*, const int*, int, hipStream_t, int, int64_t);                \
-    void pruned_perm_f##F(int, int*);                                                                                           \
+    void pruned_perm_f##F(int, int*);                                                                                     \
+    void pruned_warmup_f##F();                                                                                         \
     int pruned_twfull_len_f##F(int);                                                                                            \
     void pruned_twfull_f##F(int, const cplx*, cplx*);
 LSFC_FAMILY_DECLS(2)
@@ -30,6 +33,16 @@ static int family(int64_t L) {
     return 0;
 }
 bool pruned_length_supported(int64_t L) { return family(L) != 0; }
+
+void pruned_warmup(int device) {
+    static std::mutex mu;
+    static std::set<int> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(device)) return;
+    pruned_warmup_f2(); pruned_warmup_f3(); pruned_warmup_f5();
+    LSFC_HIP(hipDeviceSynchronize());
+    done.insert(device);
+}
 
 int pruned_best_length(int64_t n) {
     // LSFC_POW2_ONLY=1 (developer switch): power-of-two lines only, for A/B timing of the mixed-radix lines

@@ -32,6 +32,8 @@ struct PrunedTuning {
 };
 
 bool pruned_length_supported(int64_t L);
+// load the kernels' code objects on `device` (current device) once, ahead of the first pass (see fft_kernels.hip)
+void pruned_warmup(int device);
 // smallest supported line length L >= max(2n, 32): L = 2^k, 3 * 2^k or 5 * 2^k (0: none up to 2048)
 int pruned_best_length(int64_t n);
 // n (x passes), m (y passes), nin (fused pass): the actual grid size along the transformed axis, <= L/2; entries beyond
