@@ -13,9 +13,11 @@ oracle is pinned instead by independent identities that hold for the
 reference's own formulas (tests/test_oracle.py):
   * dense identity   fastconvolution == b + k^2 * buildConvMatrix * (nu .* b)
   * analytic answer  FFTconvolution(FastM3D, gaussian) == -solRefHelmholtz
+  * quadrature       FFTconvolution(FastM 2D Greengard-Vico, gaussian) == int (i/4) H0(k r) gaussian  (adaptive quadrature)
   * padding / shift identities (literal 4n == pre-shifted == reduced 2n)
 The GMRES arithmetic follows IterativeSolvers.jl (not vendored, not pinned by
-the reference) as documented upstream.
+the reference) as documented upstream; its residual histories and solutions are
+cross-checked against an independent restarted GMRES (scipy) in tests/test_oracle.py.
 
 Conventions: every grid function is a flat vector in Julia's column-major
 order (x fastest).  ``reshape(b, n, m)`` in Julia == ``b.reshape((n, m),

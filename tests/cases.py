@@ -81,3 +81,23 @@ def sparsifying_pair_2d(n, h, k, nu_flat, eps=0.5):
     As = (-(lap + (k**2 + 1j * eps) * sp.identity(N))).tocsr().astype(np.complex128)
     Msp = (As + k**2 * sp.diags(np.asarray(nu_flat, dtype=np.float64))).tocsc().astype(np.complex128)
     return Msp, As
+
+
+def gaussian_2d_quadrature_points(x, k, sig, points):
+    """Independent known answer for the 2D Greengard-Vico branch: u(p) = int (i/4) H0^(1)(k |p - y|) f(y) dy for the
+    unit-mass Gaussian f, by adaptive quadrature in polar coordinates around p (no FFT, no truncated-kernel symbol: the
+    continuous operator the reference discretises, src/FastConvolution.jl:185-231 + src/Functions.jl:40-42).
+    Returns [(i, j, u(x_i, x_j))]."""
+    import scipy.integrate as si
+    import scipy.special as sp
+
+    def value(px, py):
+        def integrand(th, r, part):
+            yx, yy = px + r * np.cos(th), py + r * np.sin(th)
+            fv = np.exp(-(yx ** 2 + yy ** 2) / (2 * sig ** 2)) / (2 * np.pi * sig ** 2)
+            v = 0.25j * sp.hankel1(0, k * r) * fv * r
+            return v.real if part == 0 else v.imag
+        re = si.dblquad(integrand, 0, 1.0, 0, 2 * np.pi, args=(0,), epsabs=1e-11, epsrel=1e-11)[0]
+        im = si.dblquad(integrand, 0, 1.0, 0, 2 * np.pi, args=(1,), epsabs=1e-11, epsrel=1e-11)[0]
+        return re + 1j * im
+    return [(i, j, value(x[i], x[j])) for i, j in points]

@@ -276,6 +276,19 @@ def test_analytic_gaussian_known_answer(lsfc):
     assert rel_err(lsfc.FFTconvolution(M, f)[ok], ref[ok]) < 1e-10
 
 
+def test_analytic_gaussian_2d_by_quadrature(lsfc):
+    # the device 2D Greengard-Vico builder + FFTconvolution against the continuous operator itself (adaptive quadrature of
+    # (i/4) H0(k r) * Gaussian at three points): no oracle, no FFT in the comparator
+    n, k, sig = 128, 20.0, 0.06
+    x, h = cases.grid(n, True)
+    M = lsfc.buildFastConvolution(x, x, h, k, o.gaussian_bump, quadRule="Greengard_Vico")
+    X, Y = o.grid2d(x, x)
+    f = np.exp(-(X ** 2 + Y ** 2) / (2 * sig ** 2)) / (2 * np.pi * sig ** 2)
+    u = lsfc.FFTconvolution(M, f.astype(complex)).reshape((n, n), order="F")
+    for i, j, exact in cases.gaussian_2d_quadrature_points(x, k, sig, [(64, 64), (74, 57), (20, 90)]):
+        assert abs(u[i, j] - exact) / abs(exact) < 1e-10, (i, j)
+
+
 def test_sample_g3d_delta_sources(lsfc):
     c = cases.case_3d("gv16")
     Mo, n = c["M"], c["n"]

@@ -37,6 +37,20 @@ def test_analytic_gaussian_3d():
     assert rel_err(u[ok], ref[ok]) < 1e-12
 
 
+def test_analytic_gaussian_2d_by_quadrature():
+    # second independent pin, for the 2D Greengard-Vico branch: FFTconvolution of a unit-mass Gaussian against the
+    # continuous integral of (i/4) H0(k r) f, evaluated by adaptive quadrature at three grid points (centre, off-centre,
+    # far corner region).  Spectral accuracy of the truncated-kernel quadrature: ~1e-15.
+    n, k, sig = 128, 20.0, 0.06
+    x, h = cases.grid(n, True)
+    M = o.build_fast_convolution(x, x, h, k, o.gaussian_bump, quadRule="Greengard_Vico")
+    X, Y = o.grid2d(x, x)
+    f = np.exp(-(X ** 2 + Y ** 2) / (2 * sig ** 2)) / (2 * np.pi * sig ** 2)
+    u = o.fft_convolution(M, f.astype(complex)).reshape((n, n), order="F")
+    for i, j, exact in cases.gaussian_2d_quadrature_points(x, k, sig, [(64, 64), (74, 57), (20, 90)]):
+        assert abs(u[i, j] - exact) / abs(exact) < 1e-11, (i, j)
+
+
 @pytest.mark.parametrize("name", ["gv33", "gv32"])
 def test_padding_identities_2d(name):
     c = cases.case_2d(name)
@@ -123,6 +137,35 @@ def test_gmres_oracle_solves_and_history_monotone():
     u2 = np.zeros(n**3, complex)
     u2, h2 = o.gmres(u2, A, rhs, Pl=lambda v: v / d, restart=5, reltol=1e-10)
     assert h2.isconverged and rel_err(u2, u) < 1e-7
+
+
+@pytest.mark.parametrize("precond", [False, True])
+def test_gmres_oracle_against_an_independent_gmres(precond):
+    # IterativeSolvers.jl is neither vendored nor pinned by the reference, so the restatement of gmres! is cross-checked
+    # against an independent implementation of the same method: restarted GMRES iterates are unique in exact arithmetic,
+    # so scipy.sparse.linalg.gmres (restart 6, left preconditioner M, one residual norm per inner step) must produce the
+    # same (preconditioned) residual history -- including across restarts -- and the same solution.
+    import scipy.sparse.linalg as spla
+    c = cases.case_3d("gv16k10")
+    Mo, n = c["M"], c["n"]
+    G2 = o.reduce_symbol(Mo.GFFT, (n, n, n))
+    A = lambda v: o.apply_reduced(G2, Mo.nu, Mo.omega, v, (n, n, n))
+    u_inc = cases.plane_wave(c["k"], c["X"])
+    rhs = -(A(u_inc) - u_inc)
+    d = 1.0 + Mo.omega ** 2 * 0.01 * Mo.nu
+    Pl = (lambda v: v / d) if precond else None
+    u = np.zeros(n ** 3, complex)
+    u, h = o.gmres(u, A, rhs, Pl=Pl, restart=6, reltol=1e-10)
+    hist = []
+    N = n ** 3
+    L = spla.LinearOperator((N, N), matvec=A, dtype=complex)
+    Mi = spla.LinearOperator((N, N), matvec=lambda v: v / d, dtype=complex) if precond else None
+    us, info = spla.gmres(L, rhs, M=Mi, restart=6, rtol=1e-10, atol=0, maxiter=20, callback=lambda r: hist.append(r), callback_type="pr_norm")
+    assert info == 0 and h.isconverged and len(hist) == h.iters > 6          # more than one restart cycle
+    scale = np.linalg.norm(rhs / d) if precond else np.linalg.norm(rhs)     # scipy reports it relative to |M b|
+    r = np.array(h.resnorm) / scale
+    assert np.max(np.abs(r - np.array(hist)) / np.array(hist)) < 1e-8
+    assert rel_err(us, u) < 1e-12
 
 
 @pytest.mark.parametrize("name", ["trap21", "gv33", "gv32", "gv128"])
