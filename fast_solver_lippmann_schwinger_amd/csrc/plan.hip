@@ -240,8 +240,38 @@ void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
             p->sym.alloc((size_t)p->pads[0] * p->sym_rows * p->sym_hz);
             pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, p->sym_hz, 0, p->pads[0] / 8, scale, p->stream);
         } else {
-            p->sym.alloc((size_t)total);
-            pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, p->pads[1], 1, 0, p->pads[0] / 8, scale, p->stream);
+            // 2D: the fused pass runs along y.  An even symbol (every Green's symbol of the reference) is stored for the
+            // frequencies ky <= Ly/2 only -- rows s < Ly/2 in storage order plus the ky = Ly/2 row -- and the fused pass
+            // fetches the mirror values through LDS exactly as the 3D pass does along z (half the symbol bytes of the pass).
+            const int Ly = p->pads[1];
+            bool even = false;
+            const char* env = getenv("LSFC_SYM_EVEN_Z");
+            if (!(env && env[0] == '0') && Ly >= 32) {
+                bool ok = true;
+                for (int s2 = 0; s2 < Ly; ++s2) if ((perm[1][(size_t)s2] < Ly / 2) != (s2 < Ly / 2)) ok = false;
+                if (ok) even = pw_mirror_deviation(G2.p, p->pads, 1, p->stream) < 1e-13;
+            }
+            if (even) {
+                std::vector<int> inv((size_t)Ly), zm((size_t)Ly / 2), rowk((size_t)Ly / 2 + 1);
+                for (int s2 = 0; s2 < Ly; ++s2) inv[(size_t)perm[1][(size_t)s2]] = s2;
+                for (int s2 = Ly / 2; s2 < Ly; ++s2) {
+                    const int km = (Ly - perm[1][(size_t)s2]) % Ly;              // in [1, Ly/2]
+                    zm[(size_t)(s2 - Ly / 2)] = (km == Ly / 2) ? Ly / 2 : inv[(size_t)km];
+                }
+                for (int s2 = 0; s2 < Ly / 2; ++s2) rowk[(size_t)s2] = perm[1][(size_t)s2];
+                rowk[(size_t)Ly / 2] = Ly / 2;
+                p->zmirror.alloc(zm.size());
+                LSFC_HIP(hipMemcpy(p->zmirror.p, zm.data(), zm.size() * sizeof(int), hipMemcpyHostToDevice));
+                DevBuf<int> drow; drow.alloc(rowk.size());
+                LSFC_HIP(hipMemcpy(drow.p, rowk.data(), rowk.size() * sizeof(int), hipMemcpyHostToDevice));
+                p->sym.alloc((size_t)p->pads[0] * rowk.size());
+                pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, drow.p, dperm[2].p, p->pads, (int)rowk.size(), 1, 0, p->pads[0] / 8, scale, p->stream);
+                LSFC_HIP(hipStreamSynchronize(p->stream));
+            } else {
+                p->zmirror.release();
+                p->sym.alloc((size_t)total);
+                pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, dperm[1].p, dperm[2].p, p->pads, p->pads[1], 1, 0, p->pads[0] / 8, scale, p->stream);
+            }
         }
         LSFC_HIP(hipStreamSynchronize(p->stream));
         G2.release();
@@ -319,7 +349,7 @@ void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
                           p->zmirror.p, l, st);
             pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p1, p2, st);
         } else {
-            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, m, st);
+            pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, p->zmirror.p, m, st);
         }
         pruned_xinv(Lx, p->tuning, p->A1.p, x, y, alpha, beta, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st);
     } else {
@@ -361,7 +391,7 @@ void plan_convolve_batch_dev(lsfc_plan* p, int nrhs, const VecBatch& vb, bool us
                       p->zmirror.p, l, st, nrhs, p->a2_elems);
         pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p1, p2, st, nrhs, p->a1_elems, p->a2_elems);
     } else {
-        pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, m, st, nrhs, p->a1_elems);
+        pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, p->zmirror.p, m, st, nrhs, p->a1_elems);
     }
     pruned_xinv(Lx, p->tuning, p->A1.p, vb, nrhs, p->a1_elems, alpha, beta, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st);
 }
@@ -761,7 +791,7 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
                                   p->ytab.p, p->zmirror.p, l, st); }});
                 stages.push_back({"yinv", (4 + 2) * N * C, [=] { pruned_yinv(Ly, p->tuning, p->A2.p, p->A1.p, p->tw[1].p, Lx, m, l, p->pitch1, p->pitch2, st); }});
             } else {
-                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, nullptr, m, st); }});
+                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, p->zmirror.p, m, st); }});
             }
             stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st); }});
         } else {

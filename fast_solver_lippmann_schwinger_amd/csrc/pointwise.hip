@@ -132,7 +132,7 @@ void pw_resample_kernel(const cplx* src, cplx* dst, const int p[3], const int q[
 __global__ void k_permute_symbol(const cplx* __restrict__ G2, cplx* __restrict__ out, const int* __restrict__ px,
                                  const int* __restrict__ pyrow, const int* __restrict__ pz, int Lx, int Ly, int Lz, int rows, int hz,
                                  int xb0, int ntiles, double scale) {
-    const int64_t total = (Lz > 1) ? (int64_t)8 * hz * rows * ntiles : (int64_t)Lx * Ly;
+    const int64_t total = (Lz > 1) ? (int64_t)8 * hz * rows * ntiles : (int64_t)Lx * rows;     // 2D: `rows` symbol rows (pyrow gives their frequency)
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         int sx, sy, kz = 0;
         bool pad = false;
@@ -204,7 +204,7 @@ void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], do
     LSFC_HIP(hipGetLastError());
 }
 void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int hz, int xb0, int ntiles, double scale, hipStream_t st) {
-    const int64_t total = (L[2] > 1) ? (int64_t)8 * hz * rows * ntiles : (int64_t)L[0] * L[1];
+    const int64_t total = (L[2] > 1) ? (int64_t)8 * hz * rows * ntiles : (int64_t)L[0] * rows;
     hipLaunchKernelGGL(k_permute_symbol, dim3(grid_for(total)), dim3(256), 0, st, G2, out, px, pyrow, pz, L[0], L[1], L[2], rows, hz, xb0, ntiles, scale);
     LSFC_HIP(hipGetLastError());
 }
