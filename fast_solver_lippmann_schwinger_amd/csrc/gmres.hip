@@ -205,7 +205,21 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
         return T.hpin()[0].x;
     };
     // h[j0..j0+k) = V[:, 0..k)' w  and  w -= V h   (classical Gram-Schmidt sweep over the first k columns), then ||w||
-    auto cgs_sweep = [&](int k) {
+    // one device, no all-reduce between a reduction and its consumer: the fused kernels (pointwise.hip) sum block partials
+    // inside the consuming kernel -- same summation order, bit-identical scalars, roughly half the launches
+    const bool fused = !T.reduce && T.mem.size() == 1;
+    auto slot = [&](int s2) { return T.mem[0].w->partial.p + (size_t)s2 * (size_t)blas_partial_slot(); };
+    auto cgs_sweep = [&](int k, bool scale_now) {
+        if (fused && k <= 64) {
+            Member& m = T.mem[0];
+            Team::dev(m);
+            blas_multidot_partial(Team::V(m, 0), m.p->N, k, Team::V(m, k), slot(0), m.p->N, m.p->stream);
+            blas_cgs_update_fused(Team::V(m, k), Team::V(m, 0), m.p->N, k, slot(0), m.w->hdev.p, slot(64), m.p->N, m.p->stream);
+            if (scale_now) blas_scale_inv_fused(Team::V(m, k), slot(64), m.w->hdev.p + k, m.p->N, m.p->stream);
+            else blas_finish_norm(slot(64), m.w->hdev.p + k, m.p->N, m.p->stream);
+            T.fetch_h(k + 1);
+            return;
+        }
         T.each([&](Member& m) {
             for (int j0 = 0; j0 < k; j0 += 64) {
                 const int kc = std::min(64, k - j0);
@@ -221,6 +235,7 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
             blas_nrm2(Team::V(m, k), m.w->partial.p, m.w->hdev.p + k, m.p->N, m.p->stream, T.reduce);
         });
         T.finish_nrm(k);
+        if (scale_now) T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, k), m.w->hdev.p + k, m.p->N, m.p->stream); });
         T.fetch_h(k + 1);
     };
 
@@ -242,7 +257,17 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
         ++mvps;
         double nrm;
         cplx* hp = T.hpin();
-        if (o.orth == LSFC_ORTH_MGS) {
+        if (o.orth == LSFC_ORTH_MGS && fused) {
+            Member& m = T.mem[0];
+            Team::dev(m);
+            blas_dot_partial(Team::V(m, 0), Team::V(m, k), slot(0), m.p->N, m.p->stream);
+            for (int i = 0; i < k; ++i)
+                blas_axpy_dot_fused(Team::V(m, k), Team::V(m, i), slot(i & 1), m.w->hdev.p + i, (i + 1 < k) ? Team::V(m, i + 1) : nullptr,
+                                    slot((i + 1) & 1), m.p->N, m.p->stream);
+            blas_scale_inv_fused(Team::V(m, k), slot(k & 1), m.w->hdev.p + k, m.p->N, m.p->stream);
+            T.fetch_h(k + 1);
+            nrm = hp[k].x;
+        } else if (o.orth == LSFC_ORTH_MGS) {
             // h_i = <V_i, w>; w -= h_i V_i, each sweep fused with the next inner product (norm after the last)
             T.each([&](Member& m) { blas_dot(Team::V(m, 0), Team::V(m, k), m.w->partial.p, m.w->hdev.p, m.p->N, m.p->stream); });
             T.allreduce(0, 1);
@@ -257,7 +282,7 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
             T.fetch_h(k + 1);
             nrm = hp[k].x;
         } else {
-            cgs_sweep(k);
+            cgs_sweep(k, o.orth == LSFC_ORTH_CGS);
             nrm = hp[k].x;
             if (o.orth == LSFC_ORTH_DGKS) {
                 // IterativeSolvers orthogonalize.jl: `while nrm < projection_size / sqrt(2)`, projection_size being
@@ -269,7 +294,7 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
                 bool again = false;
                 for (int pass = 0; nrm < proj / std::sqrt(2.0) && pass < 8; ++pass) {     // (8: guard against a stagnating loop)
                     again = true;
-                    cgs_sweep(k);
+                    cgs_sweep(k, false);
                     proj = 0.0;
                     for (int i = 0; i < k; ++i) {
                         proj += hp[i].x * hp[i].x + hp[i].y * hp[i].y;
@@ -279,8 +304,8 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
                     nrm = hp[k].x;
                 }
                 if (again) for (int i = 0; i < k; ++i) hp[i] = hsum[(size_t)i];
+                T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, k), m.w->hdev.p + k, m.p->N, m.p->stream); });
             }
-            T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, k), m.w->hdev.p + k, m.p->N, m.p->stream); });
         }
         for (int i = 0; i < k; ++i) H[i + (size_t)ldh * (k - 1)] = zc(hp[i].x, hp[i].y);
         H[k + (size_t)ldh * (k - 1)] = nrm;

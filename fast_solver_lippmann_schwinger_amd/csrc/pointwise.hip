@@ -242,6 +242,12 @@ void pw_gather_sources(const cplx* K, cplx* out, const int64_t* src, int nsrc, c
 
 static constexpr int RED_BLOCKS = 1024;
 static constexpr int RED_THREADS = 256;
+// blocks actually launched for a vector of n entries: at least ~4 entries per thread (a 48^3 grid gets 108 blocks, not 1024
+// blocks of mostly idle threads); a function of n only, so results stay run-to-run reproducible
+static inline int red_blocks(int64_t n) {
+    const int64_t b = (n + (int64_t)RED_THREADS * 4 - 1) / ((int64_t)RED_THREADS * 4);
+    return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -370,9 +376,120 @@ __global__ void k_scale_inv_dev(cplx* __restrict__ a, const cplx* __restrict__ s
     }
 }
 
+// ---- fused single-device Gram-Schmidt steps -----------------------------------------------------------------------
+// On one device no all-reduce sits between a reduction and its consumer, so the finisher launches disappear: every block
+// of the CONSUMING kernel sums the producer's block partials itself (<= 1024 values from L2, in exactly the order
+// k_finish uses, so every block -- and the host -- sees bit-identical scalars), and block 0 publishes the scalar for the
+// host.  A modified Gram-Schmidt sweep over k vectors is then k + 2 launches instead of 2k + 4, a classical one 3.
+__device__ __forceinline__ cplx finish_in_wave(const cplx* __restrict__ partial, int count) {      // all 64 lanes of one wave
+    cplx acc = make_double2(0.0, 0.0);
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < count; i += 64) { acc.x += partial[i].x; acc.y += partial[i].y; }
+    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y);
+    return make_double2(__shfl(acc.x, 0, 64), __shfl(acc.y, 0, 64));
+}
+
+// w -= h * v with h = sum(hpartial[0..nb)); then partial[b] = sum conj(vnext) * w (or |w|^2 when vnext == NULL); block 0: *hout = h
+__global__ __launch_bounds__(RED_THREADS) void k_axpy_dot_fused(cplx* __restrict__ w, const cplx* __restrict__ v, const cplx* __restrict__ hpartial, int nb,
+                                                                 cplx* __restrict__ hout, const cplx* __restrict__ vnext, cplx* __restrict__ partial, int64_t n) {
+    __shared__ cplx sh[RED_THREADS / 64];
+    __shared__ cplx hs;
+    if (threadIdx.x < 64) { const cplx h = finish_in_wave(hpartial, nb); if (threadIdx.x == 0) { hs = h; if (blockIdx.x == 0) *hout = h; } }
+    __syncthreads();
+    const cplx c = hs;
+    cplx acc = make_double2(0.0, 0.0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cplx q = v[i]; cplx x = w[i];
+        x.x -= fma(c.x, q.x, -c.y * q.y);
+        x.y -= fma(c.x, q.y, c.y * q.x);
+        w[i] = x;
+        if (vnext) {
+            const cplx u = vnext[i];
+            acc.x = fma(u.x, x.x, fma(u.y, x.y, acc.x));
+            acc.y = fma(u.x, x.y, fma(-u.y, x.x, acc.y));
+        } else {
+            acc.x = fma(x.x, x.x, fma(x.y, x.y, acc.x));
+        }
+    }
+    const cplx r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// w -= V h with h_j = sum(hpartial[j*RED_BLOCKS + 0..nb)), j < k <= 64; partial[b] = |w|^2 slice; block 0: hout[j] = h_j
+__global__ __launch_bounds__(RED_THREADS) void k_cgs_update_fused(cplx* __restrict__ w, const cplx* __restrict__ V, int64_t ldv, int k,
+                                                                   const cplx* __restrict__ hpartial, int nb, cplx* __restrict__ hout,
+                                                                   cplx* __restrict__ partial, int64_t n) {
+    __shared__ cplx sh[RED_THREADS / 64];
+    __shared__ cplx cs[64];
+    for (int j = threadIdx.x >> 6; j < k; j += RED_THREADS / 64) {
+        const cplx h = finish_in_wave(hpartial + (int64_t)j * RED_BLOCKS, nb);
+        if ((threadIdx.x & 63) == 0) { cs[j] = h; if (blockIdx.x == 0) hout[j] = h; }
+    }
+    __syncthreads();
+    cplx nrm = make_double2(0.0, 0.0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        cplx acc = make_double2(0.0, 0.0);
+        for (int j = 0; j < k; ++j) {
+            const cplx q = V[(int64_t)j * ldv + i], cj = cs[j];
+            acc.x += fma(cj.x, q.x, -cj.y * q.y);
+            acc.y += fma(cj.x, q.y, cj.y * q.x);
+        }
+        cplx x = w[i]; x.x -= acc.x; x.y -= acc.y; w[i] = x;
+        nrm.x = fma(x.x, x.x, fma(x.y, x.y, nrm.x));
+    }
+    const cplx r = block_sum(nrm, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// a *= 1 / sqrt(sum(npartial[0..nb)).x); block 0: *nout = (norm, 0)
+__global__ __launch_bounds__(RED_THREADS) void k_scale_inv_fused(cplx* __restrict__ a, const cplx* __restrict__ npartial, int nb, cplx* __restrict__ nout, int64_t n) {
+    __shared__ double ns;
+    if (threadIdx.x < 64) { const cplx s2 = finish_in_wave(npartial, nb); if (threadIdx.x == 0) { ns = sqrt(s2.x); if (blockIdx.x == 0) *nout = make_double2(ns, 0.0); } }
+    __syncthreads();
+    const double inv = 1.0 / ns;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        cplx v = a[i]; a[i] = make_double2(v.x * inv, v.y * inv);
+    }
+}
+
+int blas_red_blocks(int64_t n) { return red_blocks(n); }
+int blas_partial_slot() { return RED_BLOCKS; }
+// out.x = sqrt(sum partial[0..nb).x): the norm from its block partials (the DGKS test needs it on the host before scaling)
+void blas_finish_norm(const cplx* partial, cplx* out, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, red_blocks(n), out, 1);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_dot_partial(const cplx* a, const cplx* b, cplx* partial, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_dot_partial, dim3(red_blocks(n)), dim3(RED_THREADS), 0, st, a, b, partial, n);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_axpy_dot_fused(cplx* w, const cplx* v, const cplx* hpartial, cplx* hout, const cplx* vnext, cplx* partial, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_axpy_dot_fused, dim3(red_blocks(n)), dim3(RED_THREADS), 0, st, w, v, hpartial, red_blocks(n), hout, vnext, partial, n);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_multidot_partial(const cplx* V, int64_t ldv, int k, const cplx* w, cplx* partial, int64_t n, hipStream_t st) {
+    constexpr int NC = 8;
+    const int nb = red_blocks(n);
+    for (int j0 = 0; j0 < k; j0 += NC) {
+        const int kc = k - j0 < NC ? k - j0 : NC;
+        hipLaunchKernelGGL(k_multidot_partial<NC>, dim3(nb), dim3(RED_THREADS), 0, st, V + (int64_t)j0 * ldv, ldv, kc, w, partial + (int64_t)j0 * RED_BLOCKS, n);
+    }
+    LSFC_HIP(hipGetLastError());
+}
+void blas_cgs_update_fused(cplx* w, const cplx* V, int64_t ldv, int k, const cplx* hpartial, cplx* hout, cplx* npartial, int64_t n, hipStream_t st) {
+    LSFC_REQUIRE(k <= 64, "cgs_update: at most 64 columns");
+    hipLaunchKernelGGL(k_cgs_update_fused, dim3(red_blocks(n)), dim3(RED_THREADS), 0, st, w, V, ldv, k, hpartial, red_blocks(n), hout, npartial, n);
+    LSFC_HIP(hipGetLastError());
+}
+void blas_scale_inv_fused(cplx* a, const cplx* npartial, cplx* nout, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_scale_inv_fused, dim3(grid_for(n)), dim3(RED_THREADS), 0, st, a, npartial, red_blocks(n), nout, n);
+    LSFC_HIP(hipGetLastError());
+}
+
 void blas_dot(const cplx* a, const cplx* b, cplx* partial, cplx* out, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(k_dot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, a, b, partial, n);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, 0);
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(RED_THREADS), 0, st, a, b, partial, n);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, nb, out, 0);
     LSFC_HIP(hipGetLastError());
 }
 __global__ void k_sqrt_dev(cplx* s) { if (threadIdx.x == 0) *s = make_double2(sqrt(s->x), 0.0); }
@@ -381,23 +498,26 @@ void blas_sqrt_dev(cplx* s, hipStream_t st) {
     LSFC_HIP(hipGetLastError());
 }
 void blas_nrm2(const cplx* a, cplx* partial, cplx* out, int64_t n, hipStream_t st, bool defer_sqrt) {
-    hipLaunchKernelGGL(k_dot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, a, a, partial, n);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, defer_sqrt ? 0 : 1);
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(RED_THREADS), 0, st, a, a, partial, n);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, nb, out, defer_sqrt ? 0 : 1);
     LSFC_HIP(hipGetLastError());
 }
 void blas_axpy_dot(cplx* w, const cplx* v, const cplx* h, const cplx* vnext, cplx* partial, cplx* out, int64_t n, hipStream_t st, bool defer_sqrt) {
-    hipLaunchKernelGGL(k_axpy_dot_partial, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, w, v, h, vnext, partial, n);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, RED_BLOCKS, out, (vnext || defer_sqrt) ? 0 : 1);
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL(k_axpy_dot_partial, dim3(nb), dim3(RED_THREADS), 0, st, w, v, h, vnext, partial, n);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, partial, nb, out, (vnext || defer_sqrt) ? 0 : 1);
     LSFC_HIP(hipGetLastError());
 }
 void blas_multidot(const cplx* V, int64_t ldv, int k, const cplx* w, cplx* partial, cplx* out, int64_t n, hipStream_t st) {
     constexpr int NC = 8;
+    const int nb = red_blocks(n);
     for (int j0 = 0; j0 < k; j0 += NC) {
         const int kc = k - j0 < NC ? k - j0 : NC;
-        hipLaunchKernelGGL(k_multidot_partial<NC>, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, st, V + (int64_t)j0 * ldv, ldv, kc, w,
+        hipLaunchKernelGGL(k_multidot_partial<NC>, dim3(nb), dim3(RED_THREADS), 0, st, V + (int64_t)j0 * ldv, ldv, kc, w,
                            partial + (int64_t)j0 * RED_BLOCKS, n);
     }
-    hipLaunchKernelGGL(k_multifinish, dim3(k), dim3(64), 0, st, partial, RED_BLOCKS, out);
+    hipLaunchKernelGGL(k_multifinish, dim3(k), dim3(64), 0, st, partial, nb, out);
     LSFC_HIP(hipGetLastError());
 }
 void blas_gemv_acc(cplx* y, const cplx* V, int64_t ldv, int k, const cplx* c, double sign, int64_t n, hipStream_t st) {
@@ -413,6 +533,6 @@ void blas_scale_inv_dev(cplx* a, const cplx* s, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_scale_inv_dev, dim3(grid_for(n)), dim3(256), 0, st, a, s, n);
     LSFC_HIP(hipGetLastError());
 }
-int blas_partial_count() { return RED_BLOCKS * 64; }   // room for a 64-column multidot
+int blas_partial_count() { return RED_BLOCKS * 66; }   // 64 slots of a multidot + two more (norm partials, alternating slots of the fused sweeps)
 
 } // namespace lsfc

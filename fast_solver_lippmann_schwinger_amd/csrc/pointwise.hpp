@@ -32,6 +32,16 @@ void blas_axpy_dot(cplx* w, const cplx* v, const cplx* h, const cplx* vnext, cpl
 void blas_multidot(const cplx* V, int64_t ldv, int k, const cplx* w, cplx* partial, cplx* out, int64_t n, hipStream_t); // out[j] = V_j' * w
 void blas_gemv_acc(cplx* y, const cplx* V, int64_t ldv, int k, const cplx* c, double sign, int64_t n, hipStream_t);      // y += sign * V c
 void blas_sub(cplx* y, const cplx* a, const cplx* b, int64_t n, hipStream_t);
+// fused single-device Gram-Schmidt steps: the consumer of a reduction sums the producer's block partials itself (no finisher
+// launches); `partial` slots are blas_partial_count() / 64 = 1024 entries apart; block 0 publishes the scalars in hout / nout
+int  blas_red_blocks(int64_t n);
+int  blas_partial_slot();                       // entries between two slots of `partial`
+void blas_finish_norm(const cplx* partial, cplx* out, int64_t n, hipStream_t);
+void blas_dot_partial(const cplx* a, const cplx* b, cplx* partial, int64_t n, hipStream_t);
+void blas_axpy_dot_fused(cplx* w, const cplx* v, const cplx* hpartial, cplx* hout, const cplx* vnext, cplx* partial, int64_t n, hipStream_t);
+void blas_multidot_partial(const cplx* V, int64_t ldv, int k, const cplx* w, cplx* partial, int64_t n, hipStream_t);
+void blas_cgs_update_fused(cplx* w, const cplx* V, int64_t ldv, int k, const cplx* hpartial, cplx* hout, cplx* npartial, int64_t n, hipStream_t);
+void blas_scale_inv_fused(cplx* a, const cplx* npartial, cplx* nout, int64_t n, hipStream_t);
 void blas_scale_inv_dev(cplx* a, const cplx* s, int64_t n, hipStream_t);                                   // a /= s[0].x
 
 } // namespace lsfc
