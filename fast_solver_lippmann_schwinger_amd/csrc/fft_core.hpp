@@ -264,12 +264,21 @@ template <class C, int SA, int SB> constexpr bool exchange_wave_local(int G) {
 }
 
 // How the lines of one workgroup share LDS: address(pos) = off + (pos + pos>>PADSHIFT)*LSTR + xi
+// PADSHIFT < 0: no padding; instead the low bits of a position are XOR-ed with the bits above its block of 8, which spreads
+// the stride-8 accesses of a last radix-8 stage over the banks just as the padding does (4 interleaved 16-byte lines: the
+// four consecutive t of a 16-lane LDS cycle land in four different 64-byte bank groups in every stage of 16.8.8 /
+// 24.8.8 / 16.16.8) at no cost in LDS -- what lets two half-tile workgroups plus their twiddle tables share a CU.
 template <int LSTR_, int PADSHIFT_, bool SPLIT_> struct LdsLayout {
     static constexpr int LSTR = LSTR_, PADSHIFT = PADSHIFT_;
     static constexpr bool SPLIT = SPLIT_;
-    __device__ __forceinline__ static int addr(int off, int xi, int pos) { return off + (pos + (pos >> PADSHIFT)) * LSTR + xi; }
+    static constexpr bool SWIZZLE = PADSHIFT_ < 0;
+    static constexpr int SWZMASK = ((256 / (SPLIT_ ? 8 : 16)) / LSTR_ > 1 ? (256 / (SPLIT_ ? 8 : 16)) / LSTR_ : 1) - 1;
+    __device__ __forceinline__ static int addr(int off, int xi, int pos) {
+        if constexpr (SWIZZLE) return off + (pos ^ ((pos >> 3) & SWZMASK)) * LSTR + xi;
+        else return off + (pos + (pos >> PADSHIFT)) * LSTR + xi;
+    }
     // elements (of 8 or 16 bytes) needed per line
-    static constexpr int line_elems(int L) { return L + (L >> PADSHIFT); }
+    static constexpr int line_elems(int L) { return SWIZZLE ? L : L + (L >> (SWIZZLE ? 0 : PADSHIFT)); }
     static constexpr int elem_bytes() { return SPLIT ? 8 : 16; }
     // threads t of one line that share a wavefront (lane = xi + LSTR * t for interleaved lines, t + T * line otherwise)
     static constexpr int wave_group() { return LSTR == 1 ? 64 : (64 % LSTR == 0 ? 64 / LSTR : 1); }

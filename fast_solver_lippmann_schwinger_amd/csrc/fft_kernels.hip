@@ -22,6 +22,7 @@
 #include "pruned.hpp"
 #include <mutex>
 #include <set>
+#include <map>
 #include <utility>
 
 // This file is compiled once per family of line lengths (Makefile: -DLSFC_FAMILY=2 | 3 | 5): the power-of-two lines,
@@ -316,6 +317,12 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
     for (int e = 0; e < E / 2; ++e) if (EXACT || t + T * e < nin) d[dLine * (t + T * e)] = v[e];
 }
 
+// the XCD this wave runs on (HW_REG_XCC_ID, bits 3:0)
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+    return v & 7u;
+}
 // opaque copy of a value: the optimiser may not carry anything derived from the original across this point (used to keep
 // loop-invariant address arithmetic from being hoisted into registers that then live across the whole tile loop)
 template <class V> __device__ __forceinline__ V launder_v(V x) { asm volatile("" : "+v"(x)); return x; }
@@ -330,17 +337,54 @@ template <class P> __device__ __forceinline__ P launder_s(P x) { asm volatile(""
 // multiply), the symbol loads in flight under the forward transform as before, and the stores of the previous tile
 // drain under the next forward transform.  The stage-twiddle table and the mirror-slot table are set up once per
 // workgroup instead of once per tile.  Register pressure is that of the plain PREFETCH variant.
-template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL, bool LATE_SYM = false>
-__global__ __launch_bounds__(C::T * LINES, 1)
+// HALF: 4-line workgroups on half tiles (as k_zfused's HALF), TWO per CU: the exchange buffer of a whole 1024-point tile leaves
+// room for one workgroup only, whose eight waves then march in lock step through VALU phases and LDS phases that never
+// overlap (SQ counters at 512^3: 2.1 ms of VALU issue per SIMD + 2.2 ms of LDS array time inside a 5.3 ms pass).  Two
+// independent half-tile workgroups drift apart and fill each other's phases.  The two halves of a tile (64 B each of every
+// 128-B line) must pass through the same L2 at about the same time or every line is fetched twice; a static walk does
+// not hold that over hundreds of tiles (measured: 29 GB read instead of 17), so the work is handed out per XCD: tickets
+// c = 0, 1, 2, ... from tickets[xcd] (one atomic per workgroup and tile, fetched a whole forward transform before it is
+// needed) mean the halves of tiles xcd-th pair of each group of 8 pairs (see `locate`), so the halves of a tile -- and the
+// tile of the mirror row, which reads the same symbol rows -- go to the next workgroups of that XCD that become free.  A workgroup whose queue is exhausted moves on to the next queue (xcd + 1, ...), so every ticket of
+// every queue is drawn whatever the placement of the workgroups (and the tail balances itself); it ends when all eight
+// are exhausted.  There is no waiting on other workgroups anywhere.
+template <class C, int LINES, bool SPLIT, bool TWL, bool HALF> constexpr size_t persist_lds_bytes() {
+    using LL = LdsLayout<LINES, HALF ? -1 : 3, SPLIT>;
+    return (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes() + (TWL ? (size_t)C::TWLEN * sizeof(cplx) : 0);
+}
+template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL, bool LATE_SYM = false, bool HALF = false>
+__global__ __launch_bounds__(C::T * LINES, (HALF && 2 * persist_lds_bytes<C, LINES, SPLIT, TWL, HALF>() <= (size_t)160 * 1024) ? 2 : 1)
 void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
                       int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
-                      const int2* __restrict__ ytab, const int* __restrict__ zm, int nin, unsigned ntiles) {
-    using LL = LdsLayout<LINES, 3, SPLIT>;
+                      const int2* __restrict__ ytab, const int* __restrict__ zm, int nin, unsigned ntiles, unsigned* __restrict__ tickets) {
+    using LL = LdsLayout<LINES, HALF ? -1 : 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, H = E / 2;
-    const int xi = threadIdx.x % LINES, t = threadIdx.x / LINES, li = xi;
-    unsigned tile = blockIdx.x;
-    if (tile >= ntiles) return;                         // (uniform per workgroup; no inter-workgroup synchronisation anywhere)
+    const int li = threadIdx.x % LINES, t = threadIdx.x / LINES;
+    // work item: a tile (static walk b, b + G, ...) or, HALF, a ticket of this workgroup's XCD
+    // (HALF: a work item is (ticket << 3 | queue); DONE = nothing left anywhere)
+    constexpr unsigned DONE = 0xFFFFFFFFu;
+    unsigned cur = blockIdx.x, nwork = ntiles;
+    unsigned* slot = nullptr;                           // HALF: where thread 0 publishes the work item it drew
+    unsigned queue = 0, queues_left = 8;                // HALF, thread 0: the queue it draws from, queues not yet seen empty
+    auto draw = [&]() -> unsigned {                     // (thread 0 only)
+        while (queues_left > 0) {
+            const unsigned c = atomicAdd(tickets + queue, 1u);
+            if (c < nwork) return (c << 3) | queue;
+            queue = (queue + 1) & 7u; --queues_left;
+        }
+        return DONE;
+    };
+    if constexpr (HALF) {
+        queue = xcc_id();
+        nwork = ntiles / 4;                             // (ntiles / 8 tiles per queue) x 2 halves; the host checks ntiles % 8 == 0
+        slot = reinterpret_cast<unsigned*>(smem + persist_lds_bytes<C, LINES, SPLIT, TWL, HALF>());
+        if (threadIdx.x == 0) *slot = draw();
+        __syncthreads();
+        cur = __builtin_amdgcn_readfirstlane(*slot);
+        __syncthreads();
+        if (cur == DONE) return;
+    } else if (cur >= nwork) return;                    // (uniform per workgroup; no inter-workgroup synchronisation anywhere)
     if constexpr (TWL) {
         cplx* tl = reinterpret_cast<cplx*>(smem + (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes());
         for (int i = threadIdx.x; i < C::TWLEN; i += C::T * LINES) tl[i] = tw[i];
@@ -351,24 +395,31 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
     // 64-bit per-thread pointers kept across the loop cost the registers that decide between "fits" and "spills", and a
     // spill reload at the loop top would make the wave wait for the previous tile's stores (scratch and global memory
     // share the in-order vmcnt counter).
-    auto locate = [&](unsigned tl_, cplx*& dbase, const cplx*& sbase) {
+    auto locate = [&](unsigned w, cplx*& dbase, const cplx*& sbase) {
+        unsigned tl_ = w; int half = 0;
+        // ticket c = w >> 3 of queue q = w & 7: half c & 1 of tile 2 (q + 8 (c >> 2)) + ((c >> 1) & 1) -- four consecutive tickets
+        // are the halves of two tiles next to each other in block order, i.e. (y-even symbol) of a row and its mirror
+        if constexpr (HALF) { tl_ = 2u * ((w & 7u) + 8u * (w >> 5)) + ((w >> 4) & 1u); half = (int)((w >> 3) & 1u) * LINES; }
         const int o = (int)(tl_ % (unsigned)nouter), g = (int)(tl_ / (unsigned)nouter);
         int outer = o, srow = o;
         if (ytab) { const int2 e2 = ytab[o]; outer = e2.x; srow = e2.y; }
-        dbase = data + g * dGrp + outer * dOuter;
-        sbase = sym + g * sGrp + srow * sOuter;
+        dbase = data + g * dGrp + outer * dOuter + half;
+        sbase = sym + g * sGrp + srow * sOuter + half;
     };
     // (unsigned: scalar base + zero-extended 32-bit lane offset is an addressing mode of the global instructions)
-    const unsigned doff = (unsigned)(xi + (int)dLine * t), dstep = (unsigned)((int)dLine * T);      // element j = t + T e of this thread's line
-    const unsigned soff = (unsigned)(xi + (int)sLine * t), sstep = (unsigned)((int)sLine * T);
+    const unsigned doff = (unsigned)(li + (int)dLine * t), dstep = (unsigned)((int)dLine * T);      // element j = t + T e of this thread's line
+    const unsigned soff = (unsigned)(li + (int)sLine * t), sstep = (unsigned)((int)sLine * T);
     cplx nd[H];                                        // data of the tile about to be transformed
     {
         cplx* d; const cplx* s;
-        locate(tile, d, s);
+        locate(cur, d, s);
 #pragma unroll
         for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? d[doff + dstep * e] : make_double2(0.0, 0.0);
     }
     for (;;) {
+        // HALF: draw the next ticket now; it is published and read around the barriers of the symbol multiply below
+        unsigned drawn = 0;
+        if constexpr (HALF) { if (threadIdx.x == 0) drawn = draw(); }
         cplx v[E];
 #pragma unroll
         for (int e = 0; e < H; ++e) { v[e] = nd[e]; v[e + H] = make_double2(0.0, 0.0); }
@@ -376,7 +427,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         cplx smid = make_double2(0.0, 0.0);
         auto load_symbol = [&] {
             cplx* d; const cplx* s;
-            locate(tile, d, s);
+            locate(cur, d, s);
             const unsigned so = launder_v(soff);
 #pragma unroll
             for (int e = 0; e < H; ++e) sv[e] = s[so + sstep * e];
@@ -399,6 +450,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
 #pragma unroll
         for (int e = 0; e < H; ++e) stage[(t + T * e) * LINES + li] = sv[e];
         if (t == 0) stage[(C::L / 2) * LINES + li] = smid;
+        if constexpr (HALF) { if (threadIdx.x == 0) *slot = drawn; }
         LSFC_BARRIER();
         {
             const int* zmt = launder_s(zm) + t;            // (re-read per tile from L1: eight registers less across the loop)
@@ -408,10 +460,11 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
                 v[e + H] = cmul(v[e + H], stage[zmt[T * e] * LINES + li]);
             }
         }
-        LSFC_BARRIER();
         // next tile: its loads travel while this tile is transformed back
-        const unsigned next = tile + gridDim.x;
-        const bool more = next < ntiles;
+        unsigned next = cur + gridDim.x;
+        if constexpr (HALF) next = __builtin_amdgcn_readfirstlane(*slot);
+        LSFC_BARRIER();
+        const bool more = HALF ? next != DONE : next < nwork;
         if (more) {
             cplx* dn; const cplx* sn;
             locate(next, dn, sn);
@@ -422,13 +475,13 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         {
             cplx* d; const cplx* s;
-            locate(tile, d, s);
+            locate(cur, d, s);
             const unsigned dof = launder_v(doff);
 #pragma unroll
             for (int e = 0; e < H; ++e) if (EXACT || t + T * e < nin) d[dof + dstep * e] = v[e];
         }
         if (!more) break;
-        tile = next;
+        cur = next;
     }
 }
 
@@ -532,6 +585,11 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
 }
 
 // persistent pipelined fused pass: z-even symbol, whole 8-line tiles (3D layout); one workgroup per CU
+static int cu_count() {
+    static int cus = 0;
+    if (!cus) { int dev = 0; LSFC_HIP(hipGetDevice(&dev)); hipDeviceProp_t pr; LSFC_HIP(hipGetDeviceProperties(&pr, dev)); cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    return cus;
+}
 template <class C, bool SPLIT, bool LATE_SYM = false> static void zfused_persist_t(cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                                                             int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
                                                             const int2* ytab, const int* zm, int nin, hipStream_t st) {
@@ -546,14 +604,56 @@ template <class C, bool SPLIT, bool LATE_SYM = false> static void zfused_persist
         tw = twl;
     }
     allow_lds(k, lds);
-    static int cus = 0;
-    if (!cus) { int dev = 0; LSFC_HIP(hipGetDevice(&dev)); hipDeviceProp_t pr; LSFC_HIP(hipGetDeviceProperties(&pr, dev)); cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    const int cus = cu_count();
     const unsigned ntiles = (unsigned)((Lx / XB) * nouter);
     // workgroups per CU that fit (LDS-limited); the walk stays interleaved so that co-resident workgroups touch neighbouring tiles
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)160 * 1024) / lds));
     const unsigned grid = std::min<unsigned>(ntiles, (unsigned)(cus * per_cu));
     hipLaunchKernelGGL(k, dim3(grid), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, ntiles);
+                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, ntiles, (unsigned*)nullptr);
+}
+// Ticket counters of the half-tile pass: 8 (one per XCD) per launch, zeroed on the launch's stream just before it.  A ring of
+// 64 sets per device, so that launches in flight on different streams (chunks of a distributed plan) never share a set.
+static unsigned* ticket_set(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<int, std::pair<unsigned*, unsigned>> ring;
+    int dev = 0; LSFC_HIP(hipGetDevice(&dev));
+    unsigned* base; unsigned idx;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = ring.find(dev);
+        if (it == ring.end()) {
+            unsigned* p = nullptr;
+            LSFC_HIP(hipMalloc(&p, 64 * 8 * sizeof(unsigned)));
+            it = ring.emplace(dev, std::make_pair(p, 0u)).first;
+        }
+        base = it->second.first; idx = it->second.second++ % 64u;
+    }
+    unsigned* set = base + 8 * idx;
+    LSFC_HIP(hipMemsetAsync(set, 0, 8 * sizeof(unsigned), st));
+    return set;
+}
+// the same on half tiles: 4-line workgroups with the twiddle table, as many per CU as the LDS holds (two at L = 1024)
+template <class C> static void zfused_persist_half_t(cplx* data, const cplx* sym, const cplx* twl, int Lx, int nouter,
+                                                     int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
+                                                     const int2* ytab, const int* zm, int nin, hipStream_t st) {
+    if constexpr (C::L >= 1024) {
+        constexpr int LINES = XB / 2;
+        constexpr size_t lds = persist_lds_bytes<C, LINES, false, true, true>() + 16;   // + the ticket slot
+        static_assert(lds <= (size_t)160 * 1024, "half-tile persistent pass: exchange buffer exceeds the LDS");
+        auto k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, false, true, true, true, true> : k_zfused_persist<C, LINES, false, false, true, true, true>;
+        LSFC_REQUIRE(twl != nullptr, "half-tile persistent pass: twiddle table missing");
+        allow_lds(k, lds);
+        const unsigned ntiles = (unsigned)((Lx / XB) * nouter);
+        LSFC_REQUIRE(ntiles % 16 == 0 && nouter % 2 == 0, "ticketed half-tile z pass needs a multiple of 16 tiles in row pairs");
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 * 1024) / lds));
+        const unsigned grid = std::min<unsigned>(2 * ntiles, (unsigned)(cu_count() * per_cu));
+        unsigned* tickets = ticket_set(st);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(C::T * LINES), lds, st, data, sym, twl, nouter,
+                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, ntiles, tickets);
+    } else {
+        fail(LSFC_EINVAL, "half-tile persistent pass: lines of %d points run as whole tiles", (int)C::L);
+    }
 }
 
 // half-tile z pass (L = 1024 and L = 1536 in the 3D tiled layout only): 4-line workgroups, sibling halves 8 blocks apart
@@ -671,16 +771,26 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
         // z_persist: 1 whole-complex exchanges, 2 split exchanges, 3 / 4 the same with the symbol loaded after the first forward
         // stage (its 32 registers stay free during the widest butterfly); auto = 3: 5.24 ms at 512^3 against 5.73 for the
         // one-tile kernel, 0.58 against 0.675 ms at 256^3 (profiles/r02_experiment_persistent_zpass.log)
-        const int zp = tn.z_persist >= 0 ? tn.z_persist : 3;
+        // 5: ticketed half tiles.  Auto at L = 1536, whose whole tiles do not fit the register budget (768^3: fused pass 29.5 ->
+        // 23.7 ms, apply 56.3 -> 50.4 ms); at L = 1024 it ties with 3 (5.19-5.25 against 5.20-5.25 ms; it moves 24.0 GB instead
+        // of 25.8: paired rows meet in L2) and 3 stays (profiles/r02_experiment_ticketed_half_tiles.log)
+        const int zp = tn.z_persist >= 0 ? tn.z_persist : (L == 1536 ? 5 : 3);
         bool eight_lines = false;
         LSFC_DISPATCH_L(L, (eight_lines = Tune<C>::LINES == XB));
         // (worth it only when a workgroup walks over several tiles: below ~4 tiles per resident workgroup -- grids up to 64^3 --
         // the one-tile kernels finish sooner, 35 against 37.5 us per apply at 48^3)
         const bool enough_tiles = tn.z_persist > 0 || (int64_t)(Lx / XB) * nouter >= (int64_t)4096;
-        if (zp > 0 && zm && dLine == 8 && nrhs == 1 && eight_lines && !half_form && enough_tiles) {
+        const bool half5 = zp == 5 && tiled && twl && L >= 1024 && ((int64_t)(Lx / XB) * nouter) % 16 == 0 && nouter % 2 == 0;
+        if (zp > 0 && zm && dLine == 8 && nrhs == 1 && eight_lines && (!half_form || half5) && enough_tiles) {
             size_t full_lds = 0;
             LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<XB, 3, false>::line_elems(C::L) * XB * 16));
             const bool split = zp == 2 || zp == 4 || full_lds > (size_t)160 * 1024;
+            // 5: half tiles (4-line workgroups, swizzled unpadded exchange buffer + twiddle table), two workgroups per CU at L = 1024
+            if (half5) {
+                LSFC_DISPATCH_L(L, (zfused_persist_half_t<C>(data, sym, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st)));
+                LSFC_HIP(hipGetLastError());
+                return;
+            }
             if (zp == 3 && !split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
             else if (zp >= 3) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
             else if (split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }

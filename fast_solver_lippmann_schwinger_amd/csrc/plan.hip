@@ -177,11 +177,17 @@ void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>
     if (even) {
         std::vector<int> rowof((size_t)Ly, -1);
         for (int s = 0; s < Ly; ++s) if (perm_y[s] <= Ly / 2) { rowof[s] = (int)rowky.size(); rowky.push_back(perm_y[s]); }
+        // block order: the self-mirrored rows (ky = 0, Ly/2) first, then every row followed by its mirror -- with an even
+        // number of the former every pair sits at (2j, 2j + 1), which the ticketed fused pass relies on to send both rows
+        // of a pair through the same L2
+        for (int s = 0; s < Ly; ++s)
+            if (rowof[s] >= 0 && inv[(Ly - perm_y[s]) % Ly] == s) tab.push_back(make_int2(s, rowof[s]));
         for (int s = 0; s < Ly; ++s) {
             if (rowof[s] < 0) continue;
-            tab.push_back(make_int2(s, rowof[s]));
             const int mirror = inv[(Ly - perm_y[s]) % Ly];
-            if (mirror != s) tab.push_back(make_int2(mirror, rowof[s]));
+            if (mirror == s) continue;
+            tab.push_back(make_int2(s, rowof[s]));
+            tab.push_back(make_int2(mirror, rowof[s]));
         }
     } else {
         for (int s = 0; s < Ly; ++s) { rowky.push_back(perm_y[s]); tab.push_back(make_int2(s, s)); }

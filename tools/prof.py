@@ -18,7 +18,11 @@ VARIANTS = [("auto (persistent pipelined z pass)", {}, {}),
             ("persistent, whole-complex exchanges", {}, dict(z_persist=1)),
             ("persistent, split exchanges", {}, dict(z_persist=2)),
             ("persistent, whole, symbol after stage 0", {}, dict(z_persist=3)),
-            ("persistent, split, symbol after stage 0", {}, dict(z_persist=4))]
+            ("persistent, split, symbol after stage 0", {}, dict(z_persist=4)),
+            ("persistent half tiles, two workgroups per CU", {}, dict(z_persist=5))]
+if os.environ.get("PROF_ONLY"):
+    keep = [int(i) for i in os.environ["PROF_ONLY"].split(",")]
+    VARIANTS = [v for i, v in enumerate(VARIANTS) if i in keep]
 
 
 def run(n, reps=5):
