@@ -774,14 +774,15 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
         // 5: ticketed half tiles.  Auto at L = 1536, whose whole tiles do not fit the register budget (768^3: fused pass 29.5 ->
         // 23.7 ms, apply 56.3 -> 50.4 ms); at L = 1024 it ties with 3 (5.19-5.25 against 5.20-5.25 ms; it moves 24.0 GB instead
         // of 25.8: paired rows meet in L2) and 3 stays (profiles/r02_experiment_ticketed_half_tiles.log)
-        const int zp = tn.z_persist >= 0 ? tn.z_persist : (L == 1536 ? 5 : 3);
+        // (the 1280-point line, 20 elements per thread, likewise: 640^3 fused pass 18.5 -> 16.5 ms, apply 35.6 -> 33.6 ms)
+        const int zp = tn.z_persist >= 0 ? tn.z_persist : ((L == 1536 || L == 1280) ? 5 : 3);
         bool eight_lines = false;
         LSFC_DISPATCH_L(L, (eight_lines = Tune<C>::LINES == XB));
         // (worth it only when a workgroup walks over several tiles: below ~4 tiles per resident workgroup -- grids up to 64^3 --
         // the one-tile kernels finish sooner, 35 against 37.5 us per apply at 48^3)
         const bool enough_tiles = tn.z_persist > 0 || (int64_t)(Lx / XB) * nouter >= (int64_t)4096;
         const bool half5 = zp == 5 && tiled && twl && L >= 1024 && ((int64_t)(Lx / XB) * nouter) % 16 == 0 && nouter % 2 == 0;
-        if (zp > 0 && zm && dLine == 8 && nrhs == 1 && eight_lines && (!half_form || half5) && enough_tiles) {
+        if (zp > 0 && zm && dLine == 8 && nrhs == 1 && (eight_lines || half5) && (!half_form || half5) && enough_tiles) {
             size_t full_lds = 0;
             LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<XB, 3, false>::line_elems(C::L) * XB * 16));
             const bool split = zp == 2 || zp == 4 || full_lds > (size_t)160 * 1024;
