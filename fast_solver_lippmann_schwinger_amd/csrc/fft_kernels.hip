@@ -352,7 +352,8 @@ template <class C, int LINES, bool SPLIT, bool TWL, bool HALF> constexpr size_t 
     using LL = LdsLayout<LINES, HALF ? -1 : 3, SPLIT>;
     return (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes() + (TWL ? (size_t)C::TWLEN * sizeof(cplx) : 0);
 }
-template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL, bool LATE_SYM = false, bool HALF = false>
+// TICKETS without HALF: whole tiles handed out the same way, in pairs (row, mirror row) per XCD queue.
+template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL, bool LATE_SYM = false, bool HALF = false, bool TICKETS = HALF>
 __global__ __launch_bounds__(C::T * LINES, (HALF && 2 * persist_lds_bytes<C, LINES, SPLIT, TWL, HALF>() <= (size_t)160 * 1024) ? 2 : 1)
 void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
                       int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
@@ -375,9 +376,9 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         }
         return DONE;
     };
-    if constexpr (HALF) {
+    if constexpr (TICKETS) {
         queue = xcc_id();
-        nwork = ntiles / 4;                             // (ntiles / 8 tiles per queue) x 2 halves; the host checks ntiles % 8 == 0
+        nwork = HALF ? ntiles / 4 : ntiles / 8;         // (ntiles / 8 tiles per queue) [x 2 halves]; the host checks ntiles % 16 == 0
         slot = reinterpret_cast<unsigned*>(smem + persist_lds_bytes<C, LINES, SPLIT, TWL, HALF>());
         if (threadIdx.x == 0) *slot = draw();
         __syncthreads();
@@ -400,6 +401,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         // ticket c = w >> 3 of queue q = w & 7: half c & 1 of tile 2 (q + 8 (c >> 2)) + ((c >> 1) & 1) -- four consecutive tickets
         // are the halves of two tiles next to each other in block order, i.e. (y-even symbol) of a row and its mirror
         if constexpr (HALF) { tl_ = 2u * ((w & 7u) + 8u * (w >> 5)) + ((w >> 4) & 1u); half = (int)((w >> 3) & 1u) * LINES; }
+        else if constexpr (TICKETS) { tl_ = 2u * ((w & 7u) + 8u * (w >> 4)) + ((w >> 3) & 1u); }
         const int o = (int)(tl_ % (unsigned)nouter), g = (int)(tl_ / (unsigned)nouter);
         int outer = o, srow = o;
         if (ytab) { const int2 e2 = ytab[o]; outer = e2.x; srow = e2.y; }
@@ -419,7 +421,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
     for (;;) {
         // HALF: draw the next ticket now; it is published and read around the barriers of the symbol multiply below
         unsigned drawn = 0;
-        if constexpr (HALF) { if (threadIdx.x == 0) drawn = draw(); }
+        if constexpr (TICKETS) { if (threadIdx.x == 0) drawn = draw(); }
         cplx v[E];
 #pragma unroll
         for (int e = 0; e < H; ++e) { v[e] = nd[e]; v[e + H] = make_double2(0.0, 0.0); }
@@ -450,7 +452,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
 #pragma unroll
         for (int e = 0; e < H; ++e) stage[(t + T * e) * LINES + li] = sv[e];
         if (t == 0) stage[(C::L / 2) * LINES + li] = smid;
-        if constexpr (HALF) { if (threadIdx.x == 0) *slot = drawn; }
+        if constexpr (TICKETS) { if (threadIdx.x == 0) *slot = drawn; }
         LSFC_BARRIER();
         {
             const int* zmt = launder_s(zm) + t;            // (re-read per tile from L1: eight registers less across the loop)
@@ -462,9 +464,9 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         }
         // next tile: its loads travel while this tile is transformed back
         unsigned next = cur + gridDim.x;
-        if constexpr (HALF) next = __builtin_amdgcn_readfirstlane(*slot);
+        if constexpr (TICKETS) next = __builtin_amdgcn_readfirstlane(*slot);
         LSFC_BARRIER();
-        const bool more = HALF ? next != DONE : next < nwork;
+        const bool more = TICKETS ? next != DONE : next < nwork;
         if (more) {
             cplx* dn; const cplx* sn;
             locate(next, dn, sn);
@@ -590,19 +592,21 @@ static int cu_count() {
     if (!cus) { int dev = 0; LSFC_HIP(hipGetDevice(&dev)); hipDeviceProp_t pr; LSFC_HIP(hipGetDeviceProperties(&pr, dev)); cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     return cus;
 }
-template <class C, bool SPLIT, bool LATE_SYM = false> static void zfused_persist_t(cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
+static unsigned* ticket_set(hipStream_t st);
+template <class C, bool SPLIT, bool LATE_SYM = false, bool TICKETS = false> static void zfused_persist_t(cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                                                             int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
                                                             const int2* ytab, const int* zm, int nin, hipStream_t st) {
     constexpr int LINES = XB;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     if (twl && lds + (size_t)C::TWLEN * sizeof(cplx) > (size_t)160 * 1024) twl = nullptr;
-    auto k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false, LATE_SYM> : k_zfused_persist<C, LINES, SPLIT, false, false, LATE_SYM>;
+    auto k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false, LATE_SYM, false, TICKETS> : k_zfused_persist<C, LINES, SPLIT, false, false, LATE_SYM, false, TICKETS>;
     if (twl) {
-        k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM>;
+        k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS>;
         lds += (size_t)C::TWLEN * sizeof(cplx);
         tw = twl;
     }
+    if (TICKETS) lds += 16;                             // the ticket slot
     allow_lds(k, lds);
     const int cus = cu_count();
     const unsigned ntiles = (unsigned)((Lx / XB) * nouter);
@@ -610,7 +614,7 @@ template <class C, bool SPLIT, bool LATE_SYM = false> static void zfused_persist
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)160 * 1024) / lds));
     const unsigned grid = std::min<unsigned>(ntiles, (unsigned)(cus * per_cu));
     hipLaunchKernelGGL(k, dim3(grid), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, ntiles, (unsigned*)nullptr);
+                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, ntiles, TICKETS ? ticket_set(st) : (unsigned*)nullptr);
 }
 // Ticket counters of the half-tile pass: 8 (one per XCD) per launch, zeroed on the launch's stream just before it.  A ring of
 // 64 sets per device, so that launches in flight on different streams (chunks of a distributed plan) never share a set.
@@ -775,7 +779,9 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
         // 23.7 ms, apply 56.3 -> 50.4 ms); at L = 1024 it ties with 3 (5.19-5.25 against 5.20-5.25 ms; it moves 24.0 GB instead
         // of 25.8: paired rows meet in L2) and 3 stays (profiles/r02_experiment_ticketed_half_tiles.log)
         // (the 1280-point line, 20 elements per thread, likewise: 640^3 fused pass 18.5 -> 16.5 ms, apply 35.6 -> 33.6 ms)
-        const int zp = tn.z_persist >= 0 ? tn.z_persist : ((L == 1536 || L == 1280) ? 5 : 3);
+        // 6 = 3 with the tiles handed out by the same tickets (row pairs per XCD: both reads of a symbol row meet in one L2):
+        // 512^3 apply 12.95 -> 12.86 ms over three A/B rounds of bench.py, neutral at 256^3; auto from L = 1024 on
+        const int zp = tn.z_persist >= 0 ? tn.z_persist : ((L == 1536 || L == 1280) ? 5 : (L >= 1024 ? 6 : 3));
         bool eight_lines = false;
         LSFC_DISPATCH_L(L, (eight_lines = Tune<C>::LINES == XB));
         // (worth it only when a workgroup walks over several tiles: below ~4 tiles per resident workgroup -- grids up to 64^3 --
@@ -792,7 +798,13 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
                 LSFC_HIP(hipGetLastError());
                 return;
             }
-            if (zp == 3 && !split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
+            // 6: whole tiles (as 3) handed out by tickets in row pairs per XCD
+            if (zp == 6 && !split && ((int64_t)(Lx / XB) * nouter) % 16 == 0 && nouter % 2 == 0) {
+                LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st)));
+                LSFC_HIP(hipGetLastError());
+                return;
+            }
+            if ((zp == 3 || zp == 6) && !split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
             else if (zp >= 3) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
             else if (split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
             else       { LSFC_DISPATCH_L(L, (zfused_persist_t<C, false>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }

@@ -242,7 +242,7 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
 /* Tuning knobs of the pruned pipeline (benchmarks / autotuning), the run-time form of the LSFC_* environment
  * switches of DESIGN.md section 3: "split_x", "split_s" (re/im-split LDS exchanges of the x / y passes), "split_z",
  * "sym_prefetch", "tw_lds", "z_half" (fused pass: split exchanges, symbol prefetch, LDS-resident stage twiddles,
- * half-tile form), "z_persist" (fused pass: 0 one tile per workgroup, 1-4 persistent pipelined whole tiles, 5 ticketed
+ * half-tile form), "z_persist" (fused pass: 0 one tile per workgroup, 1-4 persistent pipelined whole tiles (6: handed out by per-XCD tickets), 5 ticketed
  * half tiles, -1 by line length), "ytile_g", "ytile_z" (block-order tile of the y passes), "batch_fuse"
  * (lsfc_apply_batch: 1 one fused pass per group of right-hand sides, 0 member by member, -1 by grid size).  Any other
  * key is LSFC_EINVAL.  Results never depend on them beyond rounding (the forms differ in how twiddles are obtained). */

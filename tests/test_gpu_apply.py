@@ -198,7 +198,7 @@ def test_every_mixed_radix_line_length_on_every_axis_3d(lsfc, L, axis):
 @pytest.mark.parametrize("L", [1024, 1280, 1536, 2048])
 def test_fused_pass_forms_even_symbol_long_z_lines(lsfc, L):
     # every form of the fused z pass on the long lines, against the oracle: one tile per workgroup (0), persistent whole
-    # tiles (3), ticketed half tiles with per-XCD queues (5; the default at L = 1280 and 1536).  They need the z-even half symbol,
+    # tiles (3), ticketed half tiles with per-XCD queues (5; the default at L = 1280 and 1536), ticketed whole tiles (6; the default at 1024).  They need the z-even half symbol,
     # i.e. a symbol that is even in every axis (as the Green's symbols are): a random one is symmetrised.
     n, m, l = 16, 16, L // 2
     rng = np.random.default_rng(L)
@@ -211,7 +211,7 @@ def test_fused_pass_forms_even_symbol_long_z_lines(lsfc, L):
     assert M.pipeline == "pruned-hip" and M.padded_dims == (2 * n, 2 * m, 2 * l)
     want = o.apply_reduced(G2, nu, 2.0, b, (n, m, l))
     got = {}
-    for form in (0, 3, 5):
+    for form in (0, 3, 5, 6):
         M.set_tuning(z_persist=form)
         got[form] = M * b
         assert rel_err(got[form], want) < TOL, form

@@ -19,7 +19,8 @@ VARIANTS = [("auto (persistent pipelined z pass)", {}, {}),
             ("persistent, split exchanges", {}, dict(z_persist=2)),
             ("persistent, whole, symbol after stage 0", {}, dict(z_persist=3)),
             ("persistent, split, symbol after stage 0", {}, dict(z_persist=4)),
-            ("persistent half tiles, two workgroups per CU", {}, dict(z_persist=5))]
+            ("persistent half tiles, two workgroups per CU", {}, dict(z_persist=5)),
+            ("persistent whole tiles by tickets", {}, dict(z_persist=6))]
 if os.environ.get("PROF_ONLY"):
     keep = [int(i) for i in os.environ["PROF_ONLY"].split(",")]
     VARIANTS = [v for i, v in enumerate(VARIANTS) if i in keep]
