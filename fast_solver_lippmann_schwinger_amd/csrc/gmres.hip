@@ -7,6 +7,7 @@
 #include "plan.hpp"
 #include "pointwise.hpp"
 #include <cmath>
+#include <cstdlib>
 #include <complex>
 #include <condition_variable>
 #include <exception>
@@ -22,6 +23,7 @@ using zc = std::complex<double>;
 GmresWorkspace::~GmresWorkspace() {
     if (hpin) (void)hipHostFree(hpin);
     if (vpin) (void)hipHostFree(vpin);
+    for (auto& e : fetched) if (e) (void)hipEventDestroy(e);
 }
 
 // vectors = false: only the pinned host vector (the root of a multi-device plan, whose Krylov basis lives in its ranks)
@@ -36,7 +38,8 @@ static GmresWorkspace* workspace(lsfc_plan* p, int restart, bool need_vpin, bool
             w->ydev.alloc((size_t)restart + 2);
             w->partial.alloc((size_t)blas_partial_count());
             w->ax.alloc((size_t)p->N);
-            LSFC_HIP(hipHostMalloc((void**)&w->hpin, ((size_t)restart + 2) * sizeof(cplx)));
+            LSFC_HIP(hipHostMalloc((void**)&w->hpin, 2 * ((size_t)restart + 2) * sizeof(cplx)));
+            for (auto& e : w->fetched) LSFC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
     }
     if (need_vpin && !p->gmres->vpin) LSFC_HIP(hipHostMalloc((void**)&p->gmres->vpin, (size_t)p->N * sizeof(cplx)));
@@ -154,14 +157,17 @@ struct Team {
         allreduce(off, 1);
         each([&](Member& m) { blas_sqrt_dev(m.w->hdev.p + off, m.p->stream); });
     }
-    // scalars of the step -> pinned host memory of member 0
-    void fetch_h(int count) {
+    // scalars of the step -> pinned host memory of member 0, slot 0 or 1: posted behind the step's kernels, awaited when
+    // the host needs them (a pipelined solve posts the next step's kernels in between)
+    void fetch_post(int count, int slot) {
         Member& m = mem[0];
         dev(m);
-        LSFC_HIP(hipMemcpyAsync(m.w->hpin, m.w->hdev.p, (size_t)count * sizeof(cplx), hipMemcpyDeviceToHost, m.p->stream));
-        LSFC_HIP(hipStreamSynchronize(m.p->stream));
+        LSFC_HIP(hipMemcpyAsync(hpin(slot), m.w->hdev.p, (size_t)count * sizeof(cplx), hipMemcpyDeviceToHost, m.p->stream));
+        LSFC_HIP(hipEventRecord(m.w->fetched[slot], m.p->stream));
     }
-    cplx* hpin() { return mem[0].w->hpin; }
+    void fetch_wait(int slot) { dev(mem[0]); LSFC_HIP(hipEventSynchronize(mem[0].w->fetched[slot])); }
+    void fetch_h(int count, int slot = 0) { fetch_post(count, slot); fetch_wait(slot); }
+    cplx* hpin(int slot = 0) { return mem[0].w->hpin + (size_t)slot * ((size_t)mem[0].w->restart + 2); }
     void sync() { each([](Member& m) { LSFC_HIP(hipStreamSynchronize(m.p->stream)); }); }
 };
 
@@ -209,7 +215,7 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
     // inside the consuming kernel -- same summation order, bit-identical scalars, roughly half the launches
     const bool fused = !T.reduce && T.mem.size() == 1;
     auto slot = [&](int s2) { return T.mem[0].w->partial.p + (size_t)s2 * (size_t)blas_partial_slot(); };
-    auto cgs_sweep = [&](int k, bool scale_now) {
+    auto cgs_sweep = [&](int k, bool scale_now, int hslot = 0, bool wait = true) {
         if (fused && k <= 64) {
             Member& m = T.mem[0];
             Team::dev(m);
@@ -217,7 +223,8 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
             blas_cgs_update_fused(Team::V(m, k), Team::V(m, 0), m.p->N, k, slot(0), m.w->hdev.p, slot(64), m.p->N, m.p->stream);
             if (scale_now) blas_scale_inv_fused(Team::V(m, k), slot(64), m.w->hdev.p + k, m.p->N, m.p->stream);
             else blas_finish_norm(slot(64), m.w->hdev.p + k, m.p->N, m.p->stream);
-            T.fetch_h(k + 1);
+            T.fetch_post(k + 1, hslot);
+            if (wait) T.fetch_wait(hslot);
             return;
         }
         T.each([&](Member& m) {
@@ -236,7 +243,8 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
         });
         T.finish_nrm(k);
         if (scale_now) T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, k), m.w->hdev.p + k, m.p->N, m.p->stream); });
-        T.fetch_h(k + 1);
+        T.fetch_post(k + 1, hslot);
+        if (wait) T.fetch_wait(hslot);
     };
 
     std::vector<zc> H((size_t)(restart + 1) * restart, zc(0));
@@ -250,62 +258,80 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
     int k = 1; int64_t iteration = 0;
     std::vector<zc> y;
 
-    while (!(iteration >= maxiter || current <= tol)) {
-        // expand!: V[:,k+1] = A V[:,k], then ldiv!(Pl, V[:,k+1])
-        T.apply([k](const Member& m) { return (const cplx*)Team::V(m, k - 1); }, [k](const Member& m) { return Team::V(m, k); });
-        precondition(k);
-        ++mvps;
-        double nrm;
-        cplx* hp = T.hpin();
+    // One step ahead: on one device nothing the host computes feeds back into the kernels of a step (the fused kernels read
+    // their scalars from device memory), so the host may post step k + 1 before it has seen the scalars of step k and the
+    // device never idles through the read-back, the Hessenberg update and the next launches.  The step posted past
+    // convergence is surplus (its column is not used); none is posted past maxiter or past the restart length.  Worth it
+    // where a step is short (small grids); off for DGKS (the host decides about the second sweep) and for callbacks of
+    // the caller (they would see one call more than the reference makes) -- the library's own device preconditioner
+    // (lsfc_precond_callback: stream-ordered, no side effects) is fine.
+    const char* lag_env = getenv("LSFC_GMRES_LOOKAHEAD");
+    const bool own_precond = o.precond_on_device && o.precond == &lsfc_precond_callback;
+    const bool lookahead = fused && !T.batcher && o.orth != LSFC_ORTH_DGKS && (!o.precond || own_precond) &&
+                           (lag_env ? atoi(lag_env) != 0 : Ntot <= ((int64_t)1 << 22));
+    // expand!: V[:,kk+1] = A V[:,kk], ldiv!(Pl, V[:,kk+1]), orthogonalise; the scalars travel to pinned slot kk & 1
+    auto post_step = [&](int kk) {
+        const int hs = kk & 1;
+        T.apply([kk](const Member& m) { return (const cplx*)Team::V(m, kk - 1); }, [kk](const Member& m) { return Team::V(m, kk); });
+        precondition(kk);
         if (o.orth == LSFC_ORTH_MGS && fused) {
             Member& m = T.mem[0];
             Team::dev(m);
-            blas_dot_partial(Team::V(m, 0), Team::V(m, k), slot(0), m.p->N, m.p->stream);
-            for (int i = 0; i < k; ++i)
-                blas_axpy_dot_fused(Team::V(m, k), Team::V(m, i), slot(i & 1), m.w->hdev.p + i, (i + 1 < k) ? Team::V(m, i + 1) : nullptr,
+            blas_dot_partial(Team::V(m, 0), Team::V(m, kk), slot(0), m.p->N, m.p->stream);
+            for (int i = 0; i < kk; ++i)
+                blas_axpy_dot_fused(Team::V(m, kk), Team::V(m, i), slot(i & 1), m.w->hdev.p + i, (i + 1 < kk) ? Team::V(m, i + 1) : nullptr,
                                     slot((i + 1) & 1), m.p->N, m.p->stream);
-            blas_scale_inv_fused(Team::V(m, k), slot(k & 1), m.w->hdev.p + k, m.p->N, m.p->stream);
-            T.fetch_h(k + 1);
-            nrm = hp[k].x;
+            blas_scale_inv_fused(Team::V(m, kk), slot(kk & 1), m.w->hdev.p + kk, m.p->N, m.p->stream);
+            T.fetch_post(kk + 1, hs);
         } else if (o.orth == LSFC_ORTH_MGS) {
             // h_i = <V_i, w>; w -= h_i V_i, each sweep fused with the next inner product (norm after the last)
-            T.each([&](Member& m) { blas_dot(Team::V(m, 0), Team::V(m, k), m.w->partial.p, m.w->hdev.p, m.p->N, m.p->stream); });
+            T.each([&](Member& m) { blas_dot(Team::V(m, 0), Team::V(m, kk), m.w->partial.p, m.w->hdev.p, m.p->N, m.p->stream); });
             T.allreduce(0, 1);
-            for (int i = 0; i < k; ++i) {
+            for (int i = 0; i < kk; ++i) {
                 T.each([&](Member& m) {
-                    blas_axpy_dot(Team::V(m, k), Team::V(m, i), m.w->hdev.p + i, (i + 1 < k) ? Team::V(m, i + 1) : nullptr, m.w->partial.p,
+                    blas_axpy_dot(Team::V(m, kk), Team::V(m, i), m.w->hdev.p + i, (i + 1 < kk) ? Team::V(m, i + 1) : nullptr, m.w->partial.p,
                                   m.w->hdev.p + i + 1, m.p->N, m.p->stream, T.reduce);
                 });
-                if (i + 1 < k) T.allreduce(i + 1, 1); else T.finish_nrm(i + 1);
+                if (i + 1 < kk) T.allreduce(i + 1, 1); else T.finish_nrm(i + 1);
             }
-            T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, k), m.w->hdev.p + k, m.p->N, m.p->stream); });
-            T.fetch_h(k + 1);
-            nrm = hp[k].x;
+            T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, kk), m.w->hdev.p + kk, m.p->N, m.p->stream); });
+            T.fetch_post(kk + 1, hs);
         } else {
-            cgs_sweep(k, o.orth == LSFC_ORTH_CGS);
-            nrm = hp[k].x;
-            if (o.orth == LSFC_ORTH_DGKS) {
-                // IterativeSolvers orthogonalize.jl: `while nrm < projection_size / sqrt(2)`, projection_size being
-                // the norm of the latest correction; the corrections accumulate into the Hessenberg column
-                double proj = 0.0;
-                for (int i = 0; i < k; ++i) proj += hp[i].x * hp[i].x + hp[i].y * hp[i].y;
-                proj = std::sqrt(proj);
-                std::vector<cplx> hsum(hp, hp + k);
-                bool again = false;
-                for (int pass = 0; nrm < proj / std::sqrt(2.0) && pass < 8; ++pass) {     // (8: guard against a stagnating loop)
-                    again = true;
-                    cgs_sweep(k, false);
-                    proj = 0.0;
-                    for (int i = 0; i < k; ++i) {
-                        proj += hp[i].x * hp[i].x + hp[i].y * hp[i].y;
-                        hsum[(size_t)i].x += hp[i].x; hsum[(size_t)i].y += hp[i].y;
-                    }
-                    proj = std::sqrt(proj);
-                    nrm = hp[k].x;
+            cgs_sweep(kk, o.orth == LSFC_ORTH_CGS, hs, false);
+        }
+    };
+
+    int posted = 0;                                         // columns of this cycle whose kernels are in the stream (>= k - 1)
+    while (!(iteration >= maxiter || current <= tol)) {
+        // steps in flight: the one the host is about to read and, with lookahead, the one after it
+        const int want = k + (lookahead ? 1 : 0);
+        while (posted < want && posted < restart && iteration + (posted - (k - 1)) < maxiter) { ++posted; post_step(posted); }
+        ++mvps;
+        double nrm;
+        cplx* hp = T.hpin(k & 1);
+        T.fetch_wait(k & 1);
+        nrm = hp[k].x;
+        if (o.orth == LSFC_ORTH_DGKS) {
+            // IterativeSolvers orthogonalize.jl: `while nrm < projection_size / sqrt(2)`, projection_size being
+            // the norm of the latest correction; the corrections accumulate into the Hessenberg column
+            double proj = 0.0;
+            for (int i = 0; i < k; ++i) proj += hp[i].x * hp[i].x + hp[i].y * hp[i].y;
+            proj = std::sqrt(proj);
+            std::vector<cplx> hsum(hp, hp + k);
+            bool again = false;
+            for (int pass = 0; nrm < proj / std::sqrt(2.0) && pass < 8; ++pass) {     // (8: guard against a stagnating loop)
+                again = true;
+                cgs_sweep(k, false, k & 1, true);
+                proj = 0.0;
+                for (int i = 0; i < k; ++i) {
+                    proj += hp[i].x * hp[i].x + hp[i].y * hp[i].y;
+                    hsum[(size_t)i].x += hp[i].x; hsum[(size_t)i].y += hp[i].y;
                 }
-                if (again) for (int i = 0; i < k; ++i) hp[i] = hsum[(size_t)i];
-                T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, k), m.w->hdev.p + k, m.p->N, m.p->stream); });
+                proj = std::sqrt(proj);
+                nrm = hp[k].x;
             }
+            if (again) for (int i = 0; i < k; ++i) hp[i] = hsum[(size_t)i];
+            T.each([&](Member& m) { blas_scale_inv_dev(Team::V(m, k), m.w->hdev.p + k, m.p->N, m.p->stream); });
         }
         for (int i = 0; i < k; ++i) H[i + (size_t)ldh * (k - 1)] = zc(hp[i].x, hp[i].y);
         H[k + (size_t)ldh * (k - 1)] = nrm;
@@ -330,7 +356,7 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
                 }
             });
             T.sync();
-            k = 1;
+            k = 1; posted = 0;
             if (!(current <= tol)) {
                 beta = init(false);
                 accumulator = 1.0;

@@ -39,8 +39,9 @@ struct GmresWorkspace {
     DevBuf<cplx> ydev;       // least-squares solution at restart
     DevBuf<cplx> partial;    // reduction scratch
     DevBuf<cplx> ax;         // A*x workspace
-    cplx* hpin = nullptr;    // pinned host mirror of hdev
+    cplx* hpin = nullptr;    // pinned host mirror of hdev: two slots of restart + 2 (the step in flight and the one before it)
     cplx* vpin = nullptr;    // pinned host vector for the preconditioner callback
+    hipEvent_t fetched[2] = { nullptr, nullptr };   // scalars of a step have landed in their slot
     ~GmresWorkspace();
 };
 

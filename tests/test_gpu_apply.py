@@ -216,6 +216,7 @@ def test_fused_pass_forms_even_symbol_long_z_lines(lsfc, L):
         got[form] = M * b
         assert rel_err(got[form], want) < TOL, form
     # twice in a row through the ticket counters (a fresh set per launch)
+    M.set_tuning(z_persist=5)
     assert np.array_equal(M * b, got[5])
 
 
