@@ -251,7 +251,8 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     // symbol: every rank evaluates the reduced symbol (elementary functions + rocFFT, ~3.5 s at 512^3) and keeps
     // only the slab of its own x' tiles in the tiled storage order
     DevBuf<cplx> G2;
-    symbol_gv3d_reduced(p.get(), box, G2);
+    const bool quarter = plan_quarter_symbol_ok(p.get());
+    if (quarter) symbol_gv3d_quarter(p.get(), box, G2); else symbol_gv3d_reduced(p.get(), box, G2);
     std::vector<int> perm[3]; DevBuf<int> dperm[3];
     for (int a = 0; a < 3; ++a) {
         perm[a].resize((size_t)p->pads[a]);
@@ -263,9 +264,10 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     const int ntiles = d->W / 8;
     const double scale = 1.0 / ((double)p->pads[0] * p->pads[1] * p->pads[2]);
     DevBuf<int> pyrow;
-    plan_setup_symbol_rows(p.get(), G2.p, perm[1], perm[2], pyrow);
+    plan_setup_symbol_rows(p.get(), quarter ? nullptr : G2.p, perm[1], perm[2], pyrow);
     p->sym.alloc((size_t)d->W * p->sym_rows * p->sym_hz);
-    pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, p->sym_hz, rank * ntiles, ntiles, scale, p->stream);
+    pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, p->sym_hz, rank * ntiles, ntiles, scale, p->stream,
+                      quarter ? p->pads[1] / 2 + 1 : 0);
     LSFC_HIP(hipStreamSynchronize(p->stream));
     G2.release();
     d->S1.alloc((size_t)p->pads[0] * m * lz);

@@ -170,7 +170,8 @@ void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>
     // served on-die by the Infinity Cache, which removes ~1/8 of the apply's HBM traffic.
     bool even = false;
     const char* env = getenv("LSFC_SYM_EVEN_Y");
-    if (!(env && env[0] == '0') && p->ndim == 3 && Ly >= 4) even = pw_mirror_deviation(G2, p->pads, 1, p->stream) < 1e-13;
+    // (G2 == NULL: the caller built the symbol through its symmetry, symbol_gv3d_quarter, and vouches for it)
+    if (!(env && env[0] == '0') && p->ndim == 3 && Ly >= 4) even = !G2 || pw_mirror_deviation(G2, p->pads, 1, p->stream) < 1e-13;
     std::vector<int> inv((size_t)Ly), rowky;
     for (int s = 0; s < Ly; ++s) inv[perm_y[s]] = s;
     std::vector<int2> tab;
@@ -207,7 +208,7 @@ void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>
     if (!(envz && envz[0] == '0') && p->ndim == 3 && Lz >= 32) {
         bool ok = true;
         for (int s2 = 0; s2 < Lz; ++s2) if ((perm_z[s2] < Lz / 2) != (s2 < Lz / 2)) ok = false;
-        if (ok) zeven = pw_mirror_deviation(G2, p->pads, 2, p->stream) < 1e-13;
+        if (ok) zeven = !G2 || pw_mirror_deviation(G2, p->pads, 2, p->stream) < 1e-13;
     }
     if (zeven) {
         std::vector<int> invz((size_t)Lz), zm((size_t)Lz / 2);
@@ -225,10 +226,29 @@ void plan_setup_symbol_rows(lsfc_plan* p, const cplx* G2, const std::vector<int>
     }
 }
 
-void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
-    // G2: natural FFT-order symbol on the grid chosen by plan_choose_reduced_grid
+// whether the pruned pipeline will store the y-even, z-even quarter of a 3D symbol that is even in every axis
+bool plan_quarter_symbol_ok(const lsfc_plan* p) {
+    if (p->ndim != 3) return false;                    // (the caller knows that the plan runs the pruned pipeline)
+    const char* ey = getenv("LSFC_SYM_EVEN_Y"); const char* ez = getenv("LSFC_SYM_EVEN_Z"); const char* full = getenv("LSFC_SYMBOL_FULL");
+    if ((ey && ey[0] == '0') || (ez && ez[0] == '0') || (full && full[0] == '1')) return false;
+    const int Ly = p->pads[1], Lz = p->pads[2];
+    if (Ly < 4 || Lz < 32 || p->pads[0] % 2 || Ly % 2 || Lz % 2) return false;
+    std::vector<int> pz((size_t)Lz);
+    pruned_perm(Lz, pz.data());
+    for (int s2 = 0; s2 < Lz; ++s2) if ((pz[(size_t)s2] < Lz / 2) != (s2 < Lz / 2)) return false;
+    return true;
+}
+
+void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) { plan_finish_symbol(p, G2, false); }
+void plan_finish_from_quarter(lsfc_plan* p, DevBuf<cplx>& Gq) { plan_finish_symbol(p, Gq, true); }
+
+void plan_finish_symbol(lsfc_plan* p, DevBuf<cplx>& G2, bool quarter) {
+    // G2: natural FFT-order symbol on the grid chosen by plan_choose_reduced_grid; quarter: only its rows ky <= Ly/2 and
+    // planes kz <= Lz/2 (symbol_gv3d_quarter)
     const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
-    LSFC_REQUIRE((int64_t)G2.n == total, "internal: reduced symbol has %lld entries, grid has %lld", (long long)G2.n, (long long)total);
+    const int64_t have = quarter ? (int64_t)p->pads[0] * (p->pads[1] / 2 + 1) * (p->pads[2] / 2 + 1) : total;
+    LSFC_REQUIRE((int64_t)G2.n == have, "internal: reduced symbol has %lld entries, expected %lld", (long long)G2.n, (long long)have);
+    LSFC_REQUIRE(!quarter || (p->pipeline == lsfc_plan::PRUNED && p->ndim == 3), "internal: quarter symbol outside the 3D pruned pipeline");
     const double scale = 1.0 / (double)total;
     if (p->pipeline == lsfc_plan::PRUNED) {
         std::vector<int> perm[3];
@@ -242,9 +262,11 @@ void plan_finish_from_reduced(lsfc_plan* p, DevBuf<cplx>& G2) {
         }
         if (p->ndim == 3) {
             DevBuf<int> pyrow;
-            plan_setup_symbol_rows(p, G2.p, perm[1], perm[2], pyrow);
+            plan_setup_symbol_rows(p, quarter ? nullptr : G2.p, perm[1], perm[2], pyrow);
+            LSFC_REQUIRE(!quarter || (p->sym_rows == p->pads[1] / 2 + 1 && p->sym_hz == p->pads[2] / 2 + 8), "internal: quarter symbol but full storage");
             p->sym.alloc((size_t)p->pads[0] * p->sym_rows * p->sym_hz);
-            pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, p->sym_hz, 0, p->pads[0] / 8, scale, p->stream);
+            pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, pyrow.p, dperm[2].p, p->pads, p->sym_rows, p->sym_hz, 0, p->pads[0] / 8, scale, p->stream,
+                              quarter ? p->pads[1] / 2 + 1 : 0);
         } else {
             // 2D: the fused pass runs along y.  An even symbol (every Green's symbol of the reference) is stored for the
             // frequencies ky <= Ly/2 only -- rows s < Ly/2 in storage order plus the ky = Ly/2 row -- and the fused pass
@@ -512,9 +534,15 @@ int lsfc_plan_create_gv3d(lsfc_plan** out, int64_t n, int64_t m, int64_t l, doub
         pt.mark("init + nu upload");
         DevBuf<cplx> G2;
         plan_choose_reduced_grid(p.get());
-        symbol_gv3d_reduced(p.get(), box, G2);
-        pt.mark("symbol (total)");
-        plan_finish_from_reduced(p.get(), G2);
+        if (p->pipeline == lsfc_plan::PRUNED && plan_quarter_symbol_ok(p.get())) {
+            symbol_gv3d_quarter(p.get(), box, G2);
+            pt.mark("symbol (total; through its symmetry)");
+            plan_finish_from_quarter(p.get(), G2);
+        } else {
+            symbol_gv3d_reduced(p.get(), box, G2);
+            pt.mark("symbol (total)");
+            plan_finish_from_reduced(p.get(), G2);
+        }
         pt.mark("tables, symbol permutation, work arrays");
         *out = p.release();
     });

@@ -158,6 +158,10 @@ void plan_common_init(lsfc_plan* p, int ndim, int64_t n, int64_t m, int64_t l, c
 
 // symbol generators (symbol.hip)
 void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2);                  // -> (2n,2m,2l) FFT order, unscaled
+void symbol_gv3d_quarter(lsfc_plan* p, double box, DevBuf<cplx>& Gq);                  // -> [Q0][Q1/2+1][Q2/2+1] (ky, kz >= 0 only), unscaled
+bool plan_quarter_symbol_ok(const lsfc_plan* p);                                       // the stored symbol is the y-even, z-even quarter
+void plan_finish_from_quarter(lsfc_plan* p, DevBuf<cplx>& Gq);
+void plan_finish_symbol(lsfc_plan* p, DevBuf<cplx>& G2, bool quarter);
 void symbol_gv2d_literal(lsfc_plan* p, double box, DevBuf<cplx>& G, int lit[3]);       // -> (4n,4m) centred
 void symbol_trap2d_literal(lsfc_plan* p, double x0, double y0, double h, cplx d0, DevBuf<cplx>& G); // -> fft(Ge), (2n-1,2m-1)
 

@@ -131,7 +131,7 @@ void pw_resample_kernel(const cplx* src, cplx* dst, const int p[3], const int q[
 // storage order (frequencies kz < Lz/2), slot Lz/2 = the kz = Lz/2 entry, the rest padding.
 __global__ void k_permute_symbol(const cplx* __restrict__ G2, cplx* __restrict__ out, const int* __restrict__ px,
                                  const int* __restrict__ pyrow, const int* __restrict__ pz, int Lx, int Ly, int Lz, int rows, int hz,
-                                 int xb0, int ntiles, double scale) {
+                                 int xb0, int ntiles, double scale, int srcLy) {
     const int64_t total = (Lz > 1) ? (int64_t)8 * hz * rows * ntiles : (int64_t)Lx * rows;     // 2D: `rows` symbol rows (pyrow gives their frequency)
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         int sx, sy, kz = 0;
@@ -146,7 +146,7 @@ __global__ void k_permute_symbol(const cplx* __restrict__ G2, cplx* __restrict__
             else pad = true;
         } else { sx = (int)(idx % Lx); sy = (int)(idx / Lx); }
         cplx v = make_double2(0.0, 0.0);
-        if (!pad) v = G2[px[sx] + (int64_t)Lx * (pyrow[sy] + (int64_t)Ly * kz)];
+        if (!pad) v = G2[px[sx] + (int64_t)Lx * (pyrow[sy] + (int64_t)srcLy * kz)];       // (srcLy < Ly: the source holds ky, kz >= 0 only)
         out[idx] = make_double2(scale * v.x, scale * v.y);
     }
 }
@@ -203,9 +203,9 @@ void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], do
     hipLaunchKernelGGL(k_wrap_crop, dim3(grid_for(total)), dim3(256), 0, st, src, dst, p[0], p[1], p[2], q[0], q[1], q[2], scale);
     LSFC_HIP(hipGetLastError());
 }
-void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int hz, int xb0, int ntiles, double scale, hipStream_t st) {
+void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int hz, int xb0, int ntiles, double scale, hipStream_t st, int srcLy) {
     const int64_t total = (L[2] > 1) ? (int64_t)8 * hz * rows * ntiles : (int64_t)L[0] * rows;
-    hipLaunchKernelGGL(k_permute_symbol, dim3(grid_for(total)), dim3(256), 0, st, G2, out, px, pyrow, pz, L[0], L[1], L[2], rows, hz, xb0, ntiles, scale);
+    hipLaunchKernelGGL(k_permute_symbol, dim3(grid_for(total)), dim3(256), 0, st, G2, out, px, pyrow, pz, L[0], L[1], L[2], rows, hz, xb0, ntiles, scale, srcLy > 0 ? srcLy : L[1]);
     LSFC_HIP(hipGetLastError());
 }
 void pw_scale(cplx* a, double s, int64_t total, hipStream_t st) {

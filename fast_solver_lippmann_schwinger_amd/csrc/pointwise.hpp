@@ -14,7 +14,8 @@ void pw_roll_scale(const cplx* src, cplx* dst, const int p[3], const int s[3], d
 void pw_resample_kernel(const cplx* src, cplx* dst, const int p[3], const int q[3], const int origin[3], const int nmax[3], double scale, hipStream_t);
 void pw_wrap_crop(const cplx* src, cplx* dst, const int p[3], const int q[3], double scale, hipStream_t);
 // 3D: tiles [xb0, xb0+ntiles) of the x' axis only (the symbol slab of one rank); 2D: whole symbol
-void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int hz, int xb0, int ntiles, double scale, hipStream_t);
+void pw_permute_symbol(const cplx* G2, cplx* out, const int* px, const int* pyrow, const int* pz, const int L[3], int rows, int hz, int xb0, int ntiles, double scale, hipStream_t,
+                       int srcLy = 0 /* rows per z plane of the source when it holds ky, kz >= 0 only (0: L[1]) */);
 // max |G(k) - G(L-k)| / max |G| along `axis` of a natural-order symbol (1.0 if it contains NaN)
 double pw_mirror_deviation(const cplx* G, const int L[3], int axis, hipStream_t);
 void pw_scale(cplx* a, double s, int64_t total, hipStream_t);

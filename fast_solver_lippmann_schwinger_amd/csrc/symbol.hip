@@ -145,6 +145,133 @@ void symbol_gv3d_reduced(lsfc_plan* p, double box, DevBuf<cplx>& G2) {
     pt.mark("symbol: free 3D plan");
 }
 
+// ---- the same symbol through its symmetry: Gtruncated3D is radial, so the literal symbol, the spatial kernel T and the
+// reduced symbol are even in every axis, and the pruned pipeline stores only the frequencies ky <= Q1/2, kz <= Q2/2 (all kx).
+// Every stage below works on the non-negative half of the axes it has not transformed yet and mirrors a half-axis to
+// full length only for the one strided rocFFT pass that consumes it:
+//   planes kz in [0, 2l] of the literal lattice -> ifft2 -> keep offsets dx in [0, Q0/2], dy in [0, Q1/2]   (1/8 of U)
+//   mirror in kz, ifft along z (length 4l), keep dz in [0, Q2/2]                                            (octant of T)
+//   mirror in dz, fft z (Q2), keep kz <= Q2/2; mirror in dy, fft y (Q1), keep ky <= Q1/2; mirror in dx, fft x (Q0)
+// Peak temporary memory at 512^3: 8.6 GB instead of 51 GB (and a quarter of the transform work); 1024^3 fits one GPU.
+// Gq[kx + Q0*(ky + (Q1/2+1)*kz)], natural order, unscaled as symbol_gv3d_reduced's G2.
+__global__ void k_crop_xy_quarter(const cplx* __restrict__ W, cplx* __restrict__ U, int P0, int P1, int P2, int Hx, int Hy, int z0, int C) {
+    const int64_t plane = (int64_t)Hx * Hy, total = plane * C;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int dx = (int)(idx % Hx); const int64_t r = idx / Hx; const int dy = (int)(r % Hy); const int c = (int)(r / Hy);
+        const int jz = z0 + c;
+        if (jz > P2 / 2) continue;
+        const cplx v = W[dx + (int64_t)P0 * (dy + (int64_t)P1 * c)];
+        U[dx + (int64_t)Hx * dy + plane * jz] = v;
+        if (jz > 0 && jz < P2 / 2) U[dx + (int64_t)Hx * dy + plane * (P2 - jz)] = v;       // the mirror plane
+    }
+}
+// dst[col + ncols*z] = scale * src[col + ncols*min(z, Q - z)], z < Q   (axis = the slowest one)
+__global__ void k_mirror_slowest(const cplx* __restrict__ src, cplx* __restrict__ dst, int64_t ncols, int Q, double scale) {
+    const int64_t total = ncols * Q;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t col = idx % ncols; const int z = (int)(idx / ncols);
+        const cplx v = src[col + ncols * (int64_t)(z <= Q / 2 ? z : Q - z)];
+        dst[idx] = make_double2(scale * v.x, scale * v.y);
+    }
+}
+// dst[dx + Hx*(y + Q1*kz)] = src[dx + Hx*(min(y, Q1 - y) + Hy*kz)]   (middle axis)
+__global__ void k_mirror_middle(const cplx* __restrict__ src, cplx* __restrict__ dst, int Hx, int Hy, int Q1, int Hz) {
+    const int64_t total = (int64_t)Hx * Q1 * Hz;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int dx = (int)(idx % Hx); const int64_t r = idx / Hx; const int y = (int)(r % Q1); const int kz = (int)(r / Q1);
+        dst[idx] = src[dx + (int64_t)Hx * ((y <= Q1 / 2 ? y : Q1 - y) + (int64_t)Hy * kz)];
+    }
+}
+// dst[x + Q0*(ky + Hy*kz)] = src[min(x, Q0 - x) + Hx*(ky + Q1*kz)], ky < Hy   (fastest axis; src rows have Q1 entries)
+__global__ void k_mirror_fastest(const cplx* __restrict__ src, cplx* __restrict__ dst, int Hx, int Q0, int Hy, int Q1, int Hz) {
+    const int64_t total = (int64_t)Q0 * Hy * Hz;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % Q0); const int64_t r = idx / Q0; const int ky = (int)(r % Hy); const int kz = (int)(r / Hy);
+        dst[idx] = src[(x <= Q0 / 2 ? x : Q0 - x) + (int64_t)Hx * (ky + (int64_t)Q1 * kz)];
+    }
+}
+
+void symbol_gv3d_quarter(lsfc_plan* p, double box, DevBuf<cplx>& Gq) {
+    const int n = p->dims[0], m = p->dims[1], l = p->dims[2];
+    const int P0 = 4 * n, P1 = 4 * m, P2 = 4 * l, Q0 = p->pads[0], Q1 = p->pads[1], Q2 = p->pads[2];
+    LSFC_REQUIRE(Q0 <= P0 && Q1 <= P1 && Q2 <= P2 && Q0 >= 2 * n && Q1 >= 2 * m && Q2 >= 2 * l, "internal: working grid outside [2n, 4n]");
+    LSFC_REQUIRE(Q0 % 2 == 0 && Q1 % 2 == 0 && Q2 % 2 == 0, "internal: odd working grid");
+    const int Hx = Q0 / 2 + 1, Hy = Q1 / 2 + 1, Hz = Q2 / 2 + 1;
+    const double Lp = 4.0 * box, L = 1.8 * box, k = p->omega;       // src/FastConvolution3D.jl:72-73
+    const double dk = 2.0 * 3.14159265358979323846 / Lp;
+    const cplx eiLk = make_double2(cos(L * k), sin(L * k));
+    const double sLk = sin(L * k);
+    const cplx limit = make_double2((sLk * eiLk.y / k) / (2.0 * k), (L - sLk * eiLk.x / k) / (2.0 * k));
+    const int patch = (p->flags & LSFC_FLAG_PATCH_SINGULAR) ? 1 : 0;
+    hipStream_t st = p->stream;
+
+    PhaseTimer pt;
+    const int64_t plane_lit = (int64_t)P0 * P1, cols = (int64_t)Hx * Hy;
+    const int planes = P2 / 2 + 1;                                  // kz = 0 .. 2l
+    int C = (int)std::max<int64_t>(1, std::min<int64_t>(planes, ((int64_t)1 << 30) / (plane_lit * (int64_t)sizeof(cplx))));
+    const int dev = p->device;
+    RocFft inv2d, inv2d_tail, invz, fwdz, fwdy, fwdx;
+    const size_t len2[2] = { (size_t)P0, (size_t)P1 };
+    const int tail = planes % C;                                    // the last chunk of planes may be shorter
+    auto on_device = [dev](auto&& body) { return std::async(std::launch::async, [dev, body] { LSFC_HIP(hipSetDevice(dev)); body(); }); };
+    auto f2d = on_device([&inv2d, &inv2d_tail, &len2, C, tail] { inv2d.create(2, len2, false, (size_t)C, true); if (tail) inv2d_tail.create(2, len2, false, (size_t)tail, true); });
+    auto fiz = on_device([&invz, P2, cols] { invz.create_strided_1d((size_t)P2, (size_t)cols, 1, (size_t)cols, false, true); });
+    auto ffz = on_device([&fwdz, Q2, cols] { fwdz.create_strided_1d((size_t)Q2, (size_t)cols, 1, (size_t)cols, true, true); });
+    auto ffy = on_device([&fwdy, Q1, Hx] { fwdy.create_strided_1d((size_t)Q1, (size_t)Hx, 1, (size_t)Hx, true, true); });
+    const size_t lenx[1] = { (size_t)Q0 };
+    auto ffx = on_device([&fwdx, &lenx, Hy, Hz] { fwdx.create(1, lenx, true, (size_t)Hy * (size_t)Hz, true); });
+    struct Joiner { std::future<void>* f[5]; ~Joiner() { for (auto* x : f) if (x->valid()) x->wait(); } } joiner{{ &f2d, &fiz, &ffz, &ffy, &ffx }};
+
+    DevBuf<cplx> U; U.alloc((size_t)(cols * P2));
+    {
+        DevBuf<cplx> W; W.alloc((size_t)(plane_lit * C));
+        f2d.get();
+        pt.mark("symbol: alloc + rocFFT 2D plan");
+        for (int z0 = 0; z0 < planes; z0 += C) {
+            const int c = std::min(C, planes - z0);
+            hipLaunchKernelGGL(k_gen_gv3d_planes, dim3(grid_for(plane_lit * c)), dim3(256), 0, st, W.p, P0, P1, P2, z0, c, dk, L, k, eiLk, patch, limit);
+            (c == C ? inv2d : inv2d_tail).exec(W.p, st);
+            hipLaunchKernelGGL(k_crop_xy_quarter, dim3(grid_for(cols * c)), dim3(256), 0, st, W.p, U.p, P0, P1, P2, Hx, Hy, z0, c);
+        }
+        LSFC_HIP(hipGetLastError());
+        LSFC_HIP(hipStreamSynchronize(st));
+        pt.mark("symbol: planes kz >= 0 (gen, ifft2, quarter crop)");
+        inv2d.release(); inv2d_tail.release();
+    }
+    fiz.get();
+    invz.exec(U.p, st);
+    LSFC_HIP(hipStreamSynchronize(st));
+    invz.release();
+    pt.mark("symbol: ifft z");
+    // octant of the spatial kernel, mirrored to Q2 along z, forward z
+    DevBuf<cplx> E1; E1.alloc((size_t)(cols * Q2));
+    hipLaunchKernelGGL(k_mirror_slowest, dim3(grid_for(cols * Q2)), dim3(256), 0, st, U.p, E1.p, cols, Q2, 1.0 / ((double)P0 * (double)P1 * (double)P2));
+    LSFC_HIP(hipGetLastError());
+    LSFC_HIP(hipStreamSynchronize(st));
+    U.release();
+    ffz.get();
+    fwdz.exec(E1.p, st);
+    // planes kz <= Q2/2 of E1, mirrored to Q1 along y, forward y plane by plane
+    DevBuf<cplx> E2; E2.alloc((size_t)Hx * Q1 * Hz);
+    hipLaunchKernelGGL(k_mirror_middle, dim3(grid_for((int64_t)Hx * Q1 * Hz)), dim3(256), 0, st, E1.p, E2.p, Hx, Hy, Q1, Hz);
+    LSFC_HIP(hipGetLastError());
+    LSFC_HIP(hipStreamSynchronize(st));
+    fwdz.release(); E1.release();
+    ffy.get();
+    for (int kz = 0; kz < Hz; ++kz) fwdy.exec(E2.p + (int64_t)Hx * Q1 * kz, st);
+    // rows ky <= Q1/2, mirrored to Q0 along x, forward x
+    Gq.alloc((size_t)Q0 * Hy * Hz);
+    hipLaunchKernelGGL(k_mirror_fastest, dim3(grid_for((int64_t)Q0 * Hy * Hz)), dim3(256), 0, st, E2.p, Gq.p, Hx, Q0, Hy, Q1, Hz);
+    LSFC_HIP(hipGetLastError());
+    LSFC_HIP(hipStreamSynchronize(st));
+    fwdy.release(); E2.release();
+    ffx.get();
+    fwdx.exec(Gq.p, st);
+    LSFC_HIP(hipStreamSynchronize(st));
+    fwdx.release();
+    pt.mark("symbol: forward z, y, x on the mirrored halves");
+}
+
 // ---- Gtruncated2D (src/Functions.jl:40-42), centred literal (4n x 4m) ---------
 __global__ void k_gen_gv2d(cplx* __restrict__ G, int P0, int P1, double dk, double L, double k, cplx a, cplx b, int patch, cplx limit) {
     const int64_t total = (int64_t)P0 * P1;

@@ -239,6 +239,30 @@ def test_mixed_radix_even_symbol_3d(lsfc):
 
 
 # ---------------------------------------------------------------------------- builders (symbol generated on the device)
+@pytest.mark.parametrize("dims", [(64, 64, 64), (24, 40, 48), (16, 96, 20)])
+def test_builder_3d_through_symmetry_equals_full_builder(lsfc, dims, monkeypatch):
+    # the default 3D builder evaluates the radial symbol on the non-negative frequencies only and mirrors half-axes
+    # (symbol_gv3d_quarter); LSFC_SYMBOL_FULL=1 selects the literal-grid builder of round 1.  Same operator to rounding,
+    # and both against the oracle.
+    n, m, l = dims
+    h = 1.0 / n
+    x, y, z = (-0.5 + h * np.arange(v) for v in (n, m, l))
+    k = 11.0
+    X, Y, Z = o.grid3d(x, y, z)
+    nuv = o.gaussian_bump(X, Y, Z)
+    b = o.random_vector(n * m * l)
+    M = lsfc.buildFastConvolution3D(x, y, z, X, Y, Z, h, k, nuv)
+    got = M * b
+    monkeypatch.setenv("LSFC_SYMBOL_FULL", "1")
+    Mf = lsfc.buildFastConvolution3D(x, y, z, X, Y, Z, h, k, nuv)
+    full = Mf * b
+    monkeypatch.delenv("LSFC_SYMBOL_FULL")
+    assert M.pipeline == Mf.pipeline == "pruned-hip" and M.padded_dims == Mf.padded_dims
+    assert rel_err(got, full) < 1e-13
+    G2 = o.reduced_symbol_gv3d(n, m, l, n * h, k, patch_singular=False)
+    assert rel_err(got, o.apply_reduced(G2, nuv, k, b, (n, m, l))) < TOL
+
+
 @pytest.mark.parametrize("name", ["trap21", "gv33", "gv32", "gv128"])
 def test_build_fast_convolution_2d(lsfc, name):
     c = cases.case_2d(name)
