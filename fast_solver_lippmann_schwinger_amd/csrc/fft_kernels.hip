@@ -508,6 +508,13 @@ template <class C> struct Tune {
     // interleave XB lines unless that would exceed 512 threads.
     static constexpr int LPW = (256 / C::T) > 0 ? (256 / C::T) : 1;
     static constexpr int LINES = (C::T * XB <= 512 || (C::E <= 8 && C::T * XB <= 1024)) ? XB : 512 / C::T;
+    // the y passes (no symbol, no second transform) of the 2048-point line: whole 128-B chunks from 1024-thread workgroups
+    // (16 waves, 128 registers each; split exchanges: 147 KB of LDS) instead of 64-B half chunks from 512 threads
+#ifdef LSFC_Y2048_HALF
+    static constexpr int YLINES = LINES;
+#else
+    static constexpr int YLINES = (C::L == 2048 && C::T * XB <= 1024) ? XB : LINES;
+#endif
 };
 
 template <class C, bool SPLIT> static void xfwd_t(const VecBatch& vb, int nrhs, int64_t obatch, const double* nu, cplx* out, const cplx* tw, int64_t nlines, int wmagic, int W, int Wp, int n, int64_t bstride, hipStream_t st) {
@@ -534,7 +541,7 @@ static void ytile(const PrunedTuning& tn, int L, int ngrp, int l, int& TG, int& 
     TZ = tn.ytile_z > 0 ? tn.ytile_z : az; if (TZ > l) TZ = l;       while (l % TZ) --TZ;
 }
 template <class C, bool SPLIT, int WPE> static void yfwd_t(const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st, int nrhs, int64_t b1, int64_t b2) {
-    constexpr int LINES = Tune<C>::LINES;
+    constexpr int LINES = Tune<C>::YLINES;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     auto k = (m == C::L / 2) ? k_yfwd<C, LINES, SPLIT, WPE, true> : k_yfwd<C, LINES, SPLIT, WPE, false>;
@@ -543,7 +550,7 @@ template <class C, bool SPLIT, int WPE> static void yfwd_t(const PrunedTuning& t
     hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * l), (unsigned)nrhs), dim3(C::T * LINES), lds, st, a1, a2, tw, Lx, m, l, TG, TZ, p1, p2, b1, b2);
 }
 template <class C, bool SPLIT, int WPE> static void yinv_t(const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st, int nrhs, int64_t b1, int64_t b2) {
-    constexpr int LINES = Tune<C>::LINES;
+    constexpr int LINES = Tune<C>::YLINES;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     auto k = (m == C::L / 2) ? k_yinv<C, LINES, SPLIT, WPE, true> : k_yinv<C, LINES, SPLIT, WPE, false>;
@@ -742,14 +749,14 @@ void FAM(pruned_xinv)(int L, const PrunedTuning& tn, const cplx* in, const VecBa
 }
 void FAM(pruned_yfwd)(int L, const PrunedTuning& tn, const cplx* a1, cplx* a2, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st, int nrhs, int64_t b1, int64_t b2) {
     size_t full_lds = 0;
-    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::LINES, 3, false>::line_elems(C::L) * Tune<C>::LINES * 16));
+    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::YLINES, 3, false>::line_elems(C::L) * Tune<C>::YLINES * 16));
     if (tn.split_s || full_lds > (size_t)160 * 1024) { LSFC_DISPATCH_L(L, (yfwd_t<C, true, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st, nrhs, b1, b2))); }
     else            { LSFC_DISPATCH_L(L, (yfwd_t<C, false, 1>(tn, a1, a2, tw, Lx, m, l, p1, p2, st, nrhs, b1, b2))); }
     LSFC_HIP(hipGetLastError());
 }
 void FAM(pruned_yinv)(int L, const PrunedTuning& tn, const cplx* a2, cplx* a1, const cplx* tw, int Lx, int m, int l, int p1, int p2, hipStream_t st, int nrhs, int64_t b1, int64_t b2) {
     size_t full_lds = 0;
-    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::LINES, 3, false>::line_elems(C::L) * Tune<C>::LINES * 16));
+    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::YLINES, 3, false>::line_elems(C::L) * Tune<C>::YLINES * 16));
     if (tn.split_s || full_lds > (size_t)160 * 1024) { LSFC_DISPATCH_L(L, (yinv_t<C, true, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st, nrhs, b1, b2))); }
     else            { LSFC_DISPATCH_L(L, (yinv_t<C, false, 1>(tn, a2, a1, tw, Lx, m, l, p1, p2, st, nrhs, b1, b2))); }
     LSFC_HIP(hipGetLastError());
@@ -781,7 +788,7 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
         // (the 1280-point line, 20 elements per thread, likewise: 640^3 fused pass 18.5 -> 16.5 ms, apply 35.6 -> 33.6 ms)
         // 6 = 3 with the tiles handed out by the same tickets (row pairs per XCD: both reads of a symbol row meet in one L2):
         // 512^3 apply 12.95 -> 12.86 ms over three A/B rounds of bench.py, neutral at 256^3; auto from L = 1024 on
-        const int zp = tn.z_persist >= 0 ? tn.z_persist : ((L == 1536 || L == 1280) ? 5 : (L >= 1024 ? 6 : 3));
+        const int zp = tn.z_persist >= 0 ? tn.z_persist : ((L == 1536 || L == 1280 || L == 2048) ? 5 : (L >= 1024 ? 6 : 3));   // (2048: 1024^3 fused pass 58.8 -> 47.0 ms)
         bool eight_lines = false;
         LSFC_DISPATCH_L(L, (eight_lines = Tune<C>::LINES == XB));
         // (worth it only when a workgroup walks over several tiles: below ~4 tiles per resident workgroup -- grids up to 64^3 --
@@ -885,7 +892,7 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
     const bool pf = tn.sym_prefetch >= 0 ? tn.sym_prefetch != 0 : e16;
     // whole-complex exchange buffers of the longest lines exceed the 160 KiB of LDS: those run split
     size_t full_lds = 0;
-    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::LINES, 3, false>::line_elems(C::L) * Tune<C>::LINES * 16));
+    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::YLINES, 3, false>::line_elems(C::L) * Tune<C>::YLINES * 16));
     if (full_lds > (size_t)160 * 1024) sp = true;
     if (sp) { if (pf) { LSFC_ZF(true, true); } else { LSFC_ZF(true, false); } }
     else    { if (pf) { LSFC_ZF(false, true); } else { LSFC_ZF(false, false); } }

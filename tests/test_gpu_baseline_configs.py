@@ -205,6 +205,35 @@ def test_n512_full_size_apply_vs_oracle(lsfc, label):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# beyond the host oracle's reach: full-size grids on the 1280- and 1536-point lines (ticketed half-tile fused pass)
+# against the closed form of G * Gaussian (src/Functions.jl:32-36; SURVEY.md 8(d) parity (iii)), at sampled points
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [640, 768])
+def test_large_grid_analytic_gaussian_at_sampled_points(lsfc, n):
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120e9:
+        pytest.skip(f"{free / 1e9:.0f} GB of device memory free: the n={n} plan and vectors need ~100 GB")
+    k, sig = 10.0, 0.05
+    x, h = _grid3(n)
+    M = lsfc.buildFastConvolution3D(x, x, x, None, None, None, h, k, np.zeros(n ** 3))
+    assert M.pipeline == "pruned-hip" and M.padded_dims == ((1280,) * 3 if n == 640 else (1536,) * 3)
+    xs = torch.from_numpy(x).cuda()
+    r2 = (xs[None, None, :] ** 2 + xs[None, :, None] ** 2 + xs[:, None, None] ** 2).reshape(-1)      # x fastest
+    f = (torch.exp(-r2 / (2 * sig ** 2)) / ((2 * np.pi) ** 1.5 * sig ** 3)).to(torch.complex128)
+    del r2
+    got = lsfc.FFTconvolution(M, f)
+    M.close()
+    idx = np.random.default_rng(n).integers(0, n ** 3, 200000)
+    X, Y, Z = x[idx % n], x[(idx // n) % n], x[idx // (n * n)]
+    with np.errstate(all="ignore"):
+        ref = -o.sol_ref_helmholtz(X, Y, Z, sig, k)
+    ok = np.isfinite(ref)
+    g = got[torch.from_numpy(idx).cuda()].cpu().numpy()
+    assert ok.sum() > 199000 and rel_err(g[ok], ref[ok]) < TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # configs[3]: the real distributed plan at n = 512 (one rank; every stream / event / RCCL call of the multi-GPU path)
 # ----------------------------------------------------------------------------------------------------------------
 def test_config3_n512_distributed_plan_bit_equal(lsfc):
