@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include "fft_configs.hpp"
 #include "pruned.hpp"
+#include <cstdlib>
 #include <mutex>
 #include <set>
 #include <map>
@@ -197,7 +198,7 @@ template <class C, int LINES, bool SPLIT, bool PREFETCH, int WPE, bool HALF, boo
 __global__ __launch_bounds__(C::T * LINES, WPE)
 void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
               int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
-              const int2* __restrict__ ytab, const int* __restrict__ zm, int nin, int nrhs, int64_t dBatch) {
+              const int2* __restrict__ ytab, const int* __restrict__ zm, int nin, int nrhs, int64_t dBatch, int sibling_pairs) {
     using LL = LdsLayout<LINES, 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E;
@@ -207,6 +208,11 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
         const unsigned b = blockIdx.x;
         tile = (b >> 4) * 8 + (b & 7);
         xi += (int)((b >> 3) & 1) * LINES;
+    } else if (sibling_pairs) {
+        // 2D layout, 4-line sub-groups: groups 2p and 2p + 1 are the two halves of the same 128-B lines.  Blocks b and b + 8
+        // (same XCD under round-robin placement) take them, so one L2 fetches each line once instead of two L2s once each.
+        const unsigned b = blockIdx.x;
+        tile = (((b >> 4) * 8 + (b & 7)) << 1) | ((b >> 3) & 1);
     }
     // block order -> (data row, symbol row): with a y-even symbol a row and its mirror share one symbol row and sit
     // next to each other in block order, so the second read of that row is served by the Infinity Cache, not HBM
@@ -583,13 +589,14 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     allow_lds(k, lds);
     if (LINES == XB) {
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / XB) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, nrhs, dBatch);
+                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, nrhs, dBatch, 0);
     } else {
         // split each tile into XB/LINES sub-groups: sub-group h starts at xi offset h*LINES
         // (tile, sub-group) collapse to one group index only when tiles are XB-contiguous in xi (2D natural layout)
         LSFC_REQUIRE(dTile == XB && sTile == XB, "sub-tile groups need the natural (2D) layout");
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab, zm, nin, nrhs, dBatch);
+                           (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab, zm, nin, nrhs, dBatch,
+                           (XB / LINES == 2 && nouter == 1 && (Lx / LINES) % 16 == 0 && !getenv("LSFC_NO_SIBLING_PAIRS")) ? 1 : 0);
     }
 }
 
@@ -679,7 +686,7 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     const int64_t ntiles = (int64_t)(Lx / XB) * nouter;
     LSFC_REQUIRE(ntiles % 8 == 0, "half-tile z pass needs a multiple of 8 tiles");
     hipLaunchKernelGGL(k, dim3((unsigned)(2 * ntiles)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, 1, (int64_t)0);
+                       dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, 1, (int64_t)0, 0);
 }
 
 #if LSFC_FAMILY == 2
