@@ -589,7 +589,10 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
     allow_lds(k, lds);
     if (LINES == XB) {
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / XB) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
-                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, nrhs, dBatch, 0);
+                           dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, nrhs, dBatch,
+                           // (pairing a row with its mirror row on one XCD here too -- blocks b and b + 8 -- measured neutral on the
+                           // one-tile and the multi-right-hand-side forms at 48^3 ... 256^3: left off)
+                           0);
     } else {
         // split each tile into XB/LINES sub-groups: sub-group h starts at xi offset h*LINES
         // (tile, sub-group) collapse to one group index only when tiles are XB-contiguous in xi (2D natural layout)
