@@ -195,20 +195,22 @@ def test_every_mixed_radix_line_length_on_every_axis_3d(lsfc, L, axis):
     assert rel_err(M * b, o.apply_reduced(G2, nu, 2.0, b, (n, m, l))) < TOL
 
 
+@pytest.mark.parametrize("short", [0, 6])
 @pytest.mark.parametrize("L", [1024, 1280, 1536, 2048])
-def test_fused_pass_forms_even_symbol_long_z_lines(lsfc, L):
+def test_fused_pass_forms_even_symbol_long_z_lines(lsfc, L, short):
     # every form of the fused z pass on the long lines, against the oracle: one tile per workgroup (0), persistent whole
     # tiles (3), ticketed half tiles with per-XCD queues (5; the default at L = 1280 and 1536), ticketed whole tiles (6; the default at 1024).  They need the z-even half symbol,
     # i.e. a symbol that is even in every axis (as the Green's symbols are): a random one is symmetrised.
-    n, m, l = 16, 16, L // 2
+    # short > 0: the z axis holds fewer points than half the line (the kernels' guarded loads and stores)
+    n, m, l = 16, 16, L // 2 - short
     rng = np.random.default_rng(L)
-    G2 = rng.standard_normal((2 * n, 2 * m, 2 * l)) + 1j * rng.standard_normal((2 * n, 2 * m, 2 * l))
+    G2 = rng.standard_normal((2 * n, 2 * m, L)) + 1j * rng.standard_normal((2 * n, 2 * m, L))
     for ax in range(3):
         G2 = 0.5 * (G2 + np.roll(np.flip(G2, axis=ax), 1, axis=ax))
     nu = rng.uniform(-0.3, 0.3, n * m * l)
     b = o.random_vector(n * m * l)
-    M = lsfc.FastM3D(np.fft.fftshift(G2), nu, 2 * n, 2 * m, 2 * l, n, m, l, 2.0)
-    assert M.pipeline == "pruned-hip" and M.padded_dims == (2 * n, 2 * m, 2 * l)
+    M = lsfc.FastM3D(np.fft.fftshift(G2), nu, 2 * n, 2 * m, L, n, m, l, 2.0)
+    assert M.pipeline == "pruned-hip" and M.padded_dims == (2 * n, 2 * m, L)
     want = o.apply_reduced(G2, nu, 2.0, b, (n, m, l))
     got = {}
     for form in (0, 3, 5, 6):
