@@ -86,7 +86,16 @@ def self_launch(argv, n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    proc = subprocess.run(launcher_command(argv, n), env=env, stdout=subprocess.PIPE, text=True)
+    # a rank that blocks for ever in a collective would otherwise hold the whole job until the driver's own limit: the launcher is
+    # given a deadline (the ranks carry their own watchdog as well, see main) and a late job is reported as failed, with its output
+    deadline = float(os.environ.get("LSFC_BENCH_DEADLINE_S", "1500"))
+    try:
+        proc = subprocess.run(launcher_command(argv, n), env=env, stdout=subprocess.PIPE, text=True, timeout=deadline)
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout if isinstance(e.stdout, str) else (e.stdout or b"").decode(errors="replace")
+        print(out, file=sys.stderr)
+        print(f"[bench] the {n}-rank job did not finish within {deadline:.0f} s (a blocked collective?); no throughput reported", file=sys.stderr, flush=True)
+        raise SystemExit(3)
     line = None
     for ln in proc.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
@@ -206,6 +215,19 @@ def main():
         self_launch(sys.argv[1:], args.gpus)             # never returns; nothing above has touched the GPU
     if "RANK" in os.environ and args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+
+    # watchdog of a multi-rank run: a rank stuck in a collective (first execution of the RCCL path on a new node) ends the job with a
+    # message instead of idling until somebody's outer limit; the thread never touches the GPU
+    if world > 1:
+        import threading
+        limit = float(os.environ.get("LSFC_BENCH_WATCHDOG_S", "1200"))
+
+        def _watchdog():
+            time.sleep(limit)
+            print(f"[bench] rank {rank}: no result after {limit:.0f} s -- giving up (blocked collective or a far slower exchange than "
+                  "modelled); no throughput reported", file=sys.stderr, flush=True)
+            os._exit(3)
+        threading.Thread(target=_watchdog, daemon=True).start()
 
     import torch
     import fast_solver_lippmann_schwinger_amd as lsfc
