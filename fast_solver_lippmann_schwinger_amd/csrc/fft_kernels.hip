@@ -205,9 +205,11 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
     int xi = threadIdx.x % LINES; const int t = threadIdx.x / LINES;
     unsigned tile = blockIdx.x;
     if constexpr (HALF) {
+        // groups of 8 tiles x (XB / LINES) parts: the parts of a tile are 8 blocks apart, i.e. on one XCD
+        constexpr int PARTS = XB / LINES, SH = PARTS == 4 ? 5 : 4;
         const unsigned b = blockIdx.x;
-        tile = (b >> 4) * 8 + (b & 7);
-        xi += (int)((b >> 3) & 1) * LINES;
+        tile = (b >> SH) * 8 + (b & 7);
+        xi += (int)((b >> 3) & (PARTS - 1)) * LINES;
     } else if (sibling_pairs) {
         // 2D layout, 4-line sub-groups: groups 2p and 2p + 1 are the two halves of the same 128-B lines.  Blocks b and b + 8
         // (same XCD under round-robin placement) take them, so one L2 fetches each line once instead of two L2s once each.
@@ -666,7 +668,7 @@ template <class C> static void zfused_persist_half_t(cplx* data, const cplx* sym
         LSFC_REQUIRE(twl != nullptr, "half-tile persistent pass: twiddle table missing");
         allow_lds(k, lds);
         const unsigned ntiles = (unsigned)((Lx / XB) * nouter);
-        LSFC_REQUIRE(ntiles % 16 == 0 && nouter % 2 == 0, "ticketed half-tile z pass needs a multiple of 16 tiles in row pairs");
+        LSFC_REQUIRE(ntiles % 16 == 0 && (nouter % 2 == 0 || !ytab), "ticketed half-tile z pass needs a multiple of 16 tiles in row pairs");
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 * 1024) / lds));
         const unsigned grid = std::min<unsigned>(2 * ntiles, (unsigned)(cu_count() * per_cu));
         unsigned* tickets = ticket_set(st);
@@ -678,17 +680,17 @@ template <class C> static void zfused_persist_half_t(cplx* data, const cplx* sym
 }
 
 // half-tile z pass (L = 1024 and L = 1536 in the 3D tiled layout only): 4-line workgroups, sibling halves 8 blocks apart
-template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static void zfused_half_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
+// (LINES = 2: quarter tiles -- four sibling workgroups per tile, 32 blocks per group of 8 tiles)
+template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false, int LINES = 4> static void zfused_half_t(cplx* data, const cplx* sym, const cplx* tw, int Lx, int nouter,
                                                          int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
                                                          const int2* ytab, const int* zm, int nin, hipStream_t st) {
-    constexpr int LINES = 4;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     const size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
     auto k = (nin == C::L / 2) ? k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true, ZE, true, false> : k_zfused<C, LINES, SPLIT, PREFETCH, WPE, true, ZE, false, false>;
     allow_lds(k, lds);
     const int64_t ntiles = (int64_t)(Lx / XB) * nouter;
     LSFC_REQUIRE(ntiles % 8 == 0, "half-tile z pass needs a multiple of 8 tiles");
-    hipLaunchKernelGGL(k, dim3((unsigned)(2 * ntiles)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
+    hipLaunchKernelGGL(k, dim3((unsigned)((XB / LINES) * ntiles)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
                        dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, 1, (int64_t)0, 0);
 }
 
@@ -804,7 +806,7 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
         // (worth it only when a workgroup walks over several tiles: below ~4 tiles per resident workgroup -- grids up to 64^3 --
         // the one-tile kernels finish sooner, 35 against 37.5 us per apply at 48^3)
         const bool enough_tiles = tn.z_persist > 0 || (int64_t)(Lx / XB) * nouter >= (int64_t)4096;
-        const bool half5 = zp == 5 && tiled && twl && L >= 1024 && ((int64_t)(Lx / XB) * nouter) % 16 == 0 && nouter % 2 == 0;
+        const bool half5 = zp == 5 && tiled && twl && L >= 1024 && ((int64_t)(Lx / XB) * nouter) % 16 == 0 && (nouter % 2 == 0 || !ytab);
         if (zp > 0 && zm && dLine == 8 && nrhs == 1 && (eight_lines || half5) && (!half_form || half5) && enough_tiles) {
             size_t full_lds = 0;
             LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<XB, 3, false>::line_elems(C::L) * XB * 16));
@@ -858,7 +860,14 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
     if (L == 2048 && dLine == 8) {
         LSFC_REQUIRE(((int64_t)(Lx / XB) * nouter) % 8 == 0, "half-tile z pass needs a multiple of 8 tiles");
         using C = Cfg2048;
-        if (zm) zfused_half_t<C, false, false, 2, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
+        // LSFC_Z_QUARTER=1 (experiment, off): quarter tiles, two 256-thread workgroups per CU (74 KB of LDS each).  Measured on
+        // the 2D tiled pass at n = 1024 (256 tiles): 35.4 against 34.2 us -- workgroups that start together run their phases
+        // together, so two per CU overlap nothing in a one-tile kernel; the ticketed persistent form (2 half tiles per
+        // workgroup) takes 54.8 us there (profiles/r02_2d_half_symbol.jsonl)
+        const char* qenv = getenv("LSFC_Z_QUARTER");
+        const bool quarter = zm && qenv && qenv[0] == '1';
+        if (quarter) zfused_half_t<C, false, false, 2, true, 2>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
+        else if (zm) zfused_half_t<C, false, false, 2, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
         else zfused_half_t<C, false, false, 2, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
         LSFC_HIP(hipGetLastError());
         return;

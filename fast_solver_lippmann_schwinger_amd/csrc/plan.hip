@@ -290,11 +290,28 @@ void plan_finish_symbol(lsfc_plan* p, DevBuf<cplx>& G2, bool quarter) {
                 rowk[(size_t)Ly / 2] = Ly / 2;
                 p->zmirror.alloc(zm.size());
                 LSFC_HIP(hipMemcpy(p->zmirror.p, zm.data(), zm.size() * sizeof(int), hipMemcpyHostToDevice));
+                // Tiled form (default from Ly = 2048 on; LSFC_2D_TILED=0|1): the x passes write / read the x'-expanded array as
+                // tiles [Lx/8][m][8] -- the chunked output they already have for the slab transposes, chunk width 8 -- so the
+                // fused pass along y finds its eight interleaved lines in ONE contiguous run of 128-B lines, exactly the 3D fused
+                // pass's situation (same kernels, same z-even symbol layout), instead of 64-B pieces a whole row apart.
+                const char* t2 = getenv("LSFC_2D_TILED");
+                const bool tiled = t2 ? t2[0] == '1' : Ly >= 2048;      // (at 1024 points the 8-line tiles are too few for the chip: 128 workgroups)
+                if (tiled && p->pads[0] % 8 == 0 && p->pads[0] <= 2048) {
+                    p->sym_hz = Ly / 2 + 8; p->sym_rows = 1;
+                    DevBuf<int> zero; zero.alloc(1);
+                    LSFC_HIP(hipMemset(zero.p, 0, sizeof(int)));
+                    const int L3[3] = { p->pads[0], 1, Ly };        // the line axis plays z; one symbol row per tile
+                    p->sym.alloc((size_t)p->pads[0] * p->sym_hz);
+                    pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, zero.p, dperm[1].p, L3, 1, p->sym_hz, 0, p->pads[0] / 8, scale, p->stream);
+                    LSFC_HIP(hipStreamSynchronize(p->stream));
+                    p->tile2d = (int64_t)8 * p->dims[1] + (Ly >= 1024 ? 72 : 0);
+                } else {
                 DevBuf<int> drow; drow.alloc(rowk.size());
                 LSFC_HIP(hipMemcpy(drow.p, rowk.data(), rowk.size() * sizeof(int), hipMemcpyHostToDevice));
                 p->sym.alloc((size_t)p->pads[0] * rowk.size());
                 pw_permute_symbol(G2.p, p->sym.p, dperm[0].p, drow.p, dperm[2].p, p->pads, (int)rowk.size(), 1, 0, p->pads[0] / 8, scale, p->stream);
                 LSFC_HIP(hipStreamSynchronize(p->stream));
+                }
             } else {
                 p->zmirror.release();
                 p->sym.alloc((size_t)total);
@@ -311,6 +328,7 @@ void plan_finish_symbol(lsfc_plan* p, DevBuf<cplx>& G2, bool quarter) {
         p->pitch1 = p->pads[0] + ((p->ndim == 3) ? pad1 / 8 * 8 : 0);
         p->pitch2 = 8 * p->dims[2] + pad2 / 8 * 8;
         p->a1_elems = (int64_t)p->pitch1 * p->dims[1] * p->dims[2];
+        if (p->tile2d) p->a1_elems = std::max<int64_t>(p->a1_elems, p->tile2d * (p->pads[0] / 8));
         p->a2_elems = (p->ndim == 3) ? (int64_t)p->pitch2 * p->pads[1] * (p->pads[0] / 8) : 0;
         p->A1.alloc((size_t)p->a1_elems);
         if (p->ndim == 3) p->A2.alloc((size_t)p->a2_elems);
@@ -360,6 +378,24 @@ void plan_finish_reduce(lsfc_plan* p, DevBuf<cplx>& Gd, const int lit[3], bool c
 // ---------------------------------------------------------------------------
 // the apply
 // ---------------------------------------------------------------------------
+// the three passes of the 2D pipeline (natural rows, or tiles: lsfc_plan::tile2d)
+static void pass2d_xfwd(lsfc_plan* p, const VecBatch& vb, int nrhs, const double* nu, hipStream_t st) {
+    const int Lx = p->pads[0], m = p->dims[1];
+    if (p->tile2d) pruned_xfwd(Lx, p->tuning, vb, nrhs, p->a1_elems, nu, p->A1.p, p->tw[0].p, m, 8, 8, p->dims[0], st, p->tile2d);
+    else pruned_xfwd(Lx, p->tuning, vb, nrhs, p->a1_elems, nu, p->A1.p, p->tw[0].p, m, Lx, p->pitch1, p->dims[0], st);
+}
+static void pass2d_yfused(lsfc_plan* p, int nrhs, hipStream_t st) {
+    const int Lx = p->pads[0], Ly = p->pads[1], m = p->dims[1];
+    if (p->tile2d) pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, p->tile2d, 0, 8, (int64_t)8 * p->sym_hz, 0, 8,
+                                 nullptr, p->zmirror.p, m, st, nrhs, p->a1_elems);
+    else pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, p->zmirror.p, m, st, nrhs, p->a1_elems);
+}
+static void pass2d_xinv(lsfc_plan* p, const VecBatch& vb, int nrhs, double alpha, double beta, hipStream_t st) {
+    const int Lx = p->pads[0], m = p->dims[1];
+    if (p->tile2d) pruned_xinv(Lx, p->tuning, p->A1.p, vb, nrhs, p->a1_elems, alpha, beta, p->tw[0].p, m, 8, 8, p->dims[0], st, p->tile2d);
+    else pruned_xinv(Lx, p->tuning, p->A1.p, vb, nrhs, p->a1_elems, alpha, beta, p->tw[0].p, m, Lx, p->pitch1, p->dims[0], st);
+}
+
 void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta) {
     const double* nu = use_nu ? p->nu.p : nullptr;
     hipStream_t st = p->stream;
@@ -368,6 +404,13 @@ void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
         const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
         const int m = p->dims[1], l = p->dims[2];
         const int64_t nlines = (int64_t)m * l;
+        if (p->ndim == 2) {
+            VecBatch vb{}; vb.x[0] = x; vb.y[0] = y;
+            pass2d_xfwd(p, vb, 1, nu, st);
+            pass2d_yfused(p, 1, st);
+            pass2d_xinv(p, vb, 1, alpha, beta, st);
+            return;
+        }
         pruned_xfwd(Lx, p->tuning, x, nu, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st);
         if (p->ndim == 3) {
             const int p1 = p->pitch1, p2 = p->pitch2;
@@ -410,6 +453,12 @@ void plan_convolve_batch_dev(lsfc_plan* p, int nrhs, const VecBatch& vb, bool us
     const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
     const int m = p->dims[1], l = p->dims[2];
     const int64_t nlines = (int64_t)m * l;
+    if (p->ndim == 2) {
+        pass2d_xfwd(p, vb, nrhs, nu, st);
+        pass2d_yfused(p, nrhs, st);
+        pass2d_xinv(p, vb, nrhs, alpha, beta, st);
+        return;
+    }
     pruned_xfwd(Lx, p->tuning, vb, nrhs, p->a1_elems, nu, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st);
     if (p->ndim == 3) {
         const int p1 = p->pitch1, p2 = p->pitch2;
@@ -817,6 +866,12 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
             const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
             const int m = p->dims[1], l = p->dims[2];
             const int64_t nlines = (int64_t)m * l;
+            if (p->ndim == 2) {
+                VecBatch vb{}; vb.x[0] = x; vb.y[0] = y;
+                stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, [=] { pass2d_xfwd(p, vb, 1, p->nu.p, st); }});
+                stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pass2d_yfused(p, 1, st); }});
+                stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pass2d_xinv(p, vb, 1, 1.0, om2, st); }});
+            } else {
             stages.push_back({"xfwd", N * (C + 8) + 2 * N * C, [=] { pruned_xfwd(Lx, p->tuning, x, p->nu.p, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st); }});
             if (p->ndim == 3) {
                 stages.push_back({"yfwd", (2 + 4) * N * C, [=] { pruned_yfwd(Ly, p->tuning, p->A1.p, p->A2.p, p->tw[1].p, Lx, m, l, p->pitch1, p->pitch2, st); }});
@@ -828,6 +883,7 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
                 stages.push_back({"yfused", (2 + 4 + 2) * N * C, [=] { pruned_zfused(Ly, p->tuning, p->A1.p, p->sym.p, p->tw[1].p, p->twl[1].p, Lx, 1, 8, 0, p->pitch1, 8, 0, Lx, nullptr, p->zmirror.p, m, st); }});
             }
             stages.push_back({"xinv", (2 + 1 + 1) * N * C, [=] { pruned_xinv(Lx, p->tuning, p->A1.p, x, y, 1.0, om2, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st); }});
+            }
         } else {
             const int64_t total = (int64_t)p->pads[0] * p->pads[1] * p->pads[2];
             const double P = (double)total;

@@ -108,6 +108,7 @@ struct lsfc_plan {
     int sym_hz = 0;
     lsfc::DevBuf<int> zmirror;
     int pitch1 = 0, pitch2 = 0;      // row pitch of A1 (>= Lx) and of one storage-y row of an A2 tile (>= 8*l)
+    int64_t tile2d = 0;              // 2D with an even symbol: A1 as tiles [Lx/8][m][8] of this pitch (elements); 0: natural rows [m][Lx]
     // several right-hand sides per launch (lsfc_apply_batch, lsfc_gmres_batch): A1 / A2 hold batch_cap members of
     // a1_elems / a2_elems entries back to back (grown on demand)
     int64_t a1_elems = 0, a2_elems = 0;
