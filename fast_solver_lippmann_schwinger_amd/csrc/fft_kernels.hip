@@ -511,6 +511,10 @@ template <class K> static void allow_lds(K kernel, size_t bytes) {
     done.insert(key);
 }
 
+// developer switches read once per process (the launch paths run per apply)
+static bool env_flag_no_sibling_pairs() { static const bool v = getenv("LSFC_NO_SIBLING_PAIRS") != nullptr; return v; }
+static bool env_flag_z_quarter() { static const bool v = [] { const char* e = getenv("LSFC_Z_QUARTER"); return e && e[0] == '1'; }(); return v; }
+
 template <class C> struct Tune {
     // lines per workgroup: contiguous passes use 256-thread workgroups; strided passes
     // interleave XB lines unless that would exceed 512 threads.
@@ -601,7 +605,7 @@ template <class C, bool SPLIT, bool PREFETCH, int WPE, bool ZE = false> static v
         LSFC_REQUIRE(dTile == XB && sTile == XB, "sub-tile groups need the natural (2D) layout");
         hipLaunchKernelGGL(k, dim3((unsigned)((Lx / LINES) * nouter)), dim3(C::T * LINES), lds, st, data, sym, tw, nouter,
                            (int64_t)LINES, dOuter, dLine, (int64_t)LINES, sOuter, sLine, ytab, zm, nin, nrhs, dBatch,
-                           (XB / LINES == 2 && nouter == 1 && (Lx / LINES) % 16 == 0 && !getenv("LSFC_NO_SIBLING_PAIRS")) ? 1 : 0);
+                           (XB / LINES == 2 && nouter == 1 && (Lx / LINES) % 16 == 0 && !env_flag_no_sibling_pairs()) ? 1 : 0);
     }
 }
 
@@ -864,8 +868,7 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
         // the 2D tiled pass at n = 1024 (256 tiles): 35.4 against 34.2 us -- workgroups that start together run their phases
         // together, so two per CU overlap nothing in a one-tile kernel; the ticketed persistent form (2 half tiles per
         // workgroup) takes 54.8 us there (profiles/r02_2d_half_symbol.jsonl)
-        const char* qenv = getenv("LSFC_Z_QUARTER");
-        const bool quarter = zm && qenv && qenv[0] == '1';
+        const bool quarter = zm && env_flag_z_quarter();
         if (quarter) zfused_half_t<C, false, false, 2, true, 2>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
         else if (zm) zfused_half_t<C, false, false, 2, true>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
         else zfused_half_t<C, false, false, 2, false>(data, sym, tw, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st);
