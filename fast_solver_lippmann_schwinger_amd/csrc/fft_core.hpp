@@ -356,7 +356,10 @@ template <class C, class LL> constexpr bool forward_ends_local() {
 // q >= R/2 zero; 2 inverse with only outputs q < R/2 wanted.
 // TWFULL: `tw` is the full stage-twiddle table (Cfg::TWOFF layout, normally staged in LDS): every power is read,
 // none is computed -- trades the product trees' fp64 work for LDS reads.
-template <class C, int S, int DIR, int PRUNE, bool TWFULL = false>
+// TWCHAIN (computed twiddles only): the powers w1^q are produced one after the other, w1^q = w1^(q-1) * w1, and applied at once
+// -- two complex numbers live instead of the R of the product tree, at an error of ~q ulp in the q-th power instead of ~4 ulp
+// (3e-15 at radix 16).  For the passes that would otherwise spill (1024-thread workgroups, 128 registers).
+template <class C, int S, int DIR, int PRUNE, bool TWFULL = false, bool TWCHAIN = false>
 __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __restrict__ tw) {
     constexpr int LS = C::template LS<S>(), R = C::template R<S>();
     constexpr int M = LS / R, NB = C::E / R;
@@ -392,6 +395,23 @@ __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __rest
 #endif
                 }
             }
+        } else if constexpr (TWCHAIN && M > 1) {
+            const int r = (t + C::T * u) % M;
+            cplx w1 = tw[r * (C::L / LS)];
+            if constexpr (DIR < 0) w1 = cconj(w1);
+            if constexpr (DIR < 0) {
+                cplx wq = w1;
+#pragma unroll
+                for (int q = 1; q < R; ++q) { a[q] = cmul(a[q], wq); if (q + 1 < R) wq = cmul(wq, w1); }
+            }
+            if constexpr (PRUNE == 1) dft_halfzero<R, DIR>(a);
+            else if constexpr (PRUNE == 2) dft_halfout<R, DIR>(a);
+            else Dft<R, DIR>::run(a);
+            if constexpr (DIR > 0) {
+                cplx wq = w1;
+#pragma unroll
+                for (int q = 1; q < R; ++q) { a[q] = cmul(a[q], wq); if (q + 1 < R) wq = cmul(wq, w1); }
+            }
         } else {
         cplx w[R];
         if constexpr (M > 1) {
@@ -419,35 +439,35 @@ __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __rest
 
 #ifndef LSFC_FFT_HOST_EMULATION
 // natural (time) order in slots -> storage (digit-reversed frequency) order in slots
-template <class C, class LL, bool PRUNE_IN, bool TWFULL = false>
+template <class C, class LL, bool PRUNE_IN, bool TWFULL = false, bool TWCHAIN = false>
 __device__ __forceinline__ void fft_forward(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
-    stage<C, 0, +1, PRUNE_IN ? 1 : 0, TWFULL>(v, t, tw);
+    stage<C, 0, +1, PRUNE_IN ? 1 : 0, TWFULL, TWCHAIN>(v, t, tw);
     exchange<C, 0, 1, LL>(v, t, smem, off, xi);
-    stage<C, 1, +1, 0, TWFULL>(v, t, tw);
+    stage<C, 1, +1, 0, TWFULL, TWCHAIN>(v, t, tw);
     if constexpr (C::NS >= 3) {
         exchange<C, 1, 2, LL>(v, t, smem, off, xi);
-        stage<C, 2, +1, 0, TWFULL>(v, t, tw);
+        stage<C, 2, +1, 0, TWFULL, TWCHAIN>(v, t, tw);
     }
     if constexpr (C::NS >= 4) {
         exchange<C, 2, 3, LL>(v, t, smem, off, xi);
-        stage<C, 3, +1, 0, TWFULL>(v, t, tw);
+        stage<C, 3, +1, 0, TWFULL, TWCHAIN>(v, t, tw);
     }
 }
 
 // storage order in slots -> natural (time) order in slots, unnormalised
-template <class C, class LL, bool PRUNE_OUT, bool TWFULL = false>
+template <class C, class LL, bool PRUNE_OUT, bool TWFULL = false, bool TWCHAIN = false>
 __device__ __forceinline__ void fft_inverse(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
     if constexpr (C::NS >= 4) {
-        stage<C, 3, -1, 0, TWFULL>(v, t, tw);
+        stage<C, 3, -1, 0, TWFULL, TWCHAIN>(v, t, tw);
         exchange<C, 3, 2, LL>(v, t, smem, off, xi);
     }
     if constexpr (C::NS >= 3) {
-        stage<C, 2, -1, 0, TWFULL>(v, t, tw);
+        stage<C, 2, -1, 0, TWFULL, TWCHAIN>(v, t, tw);
         exchange<C, 2, 1, LL>(v, t, smem, off, xi);
     }
-    stage<C, 1, -1, 0, TWFULL>(v, t, tw);
+    stage<C, 1, -1, 0, TWFULL, TWCHAIN>(v, t, tw);
     exchange<C, 1, 0, LL>(v, t, smem, off, xi);
-    stage<C, 0, -1, PRUNE_OUT ? 2 : 0, TWFULL>(v, t, tw);
+    stage<C, 0, -1, PRUNE_OUT ? 2 : 0, TWFULL, TWCHAIN>(v, t, tw);
 }
 #endif // !LSFC_FFT_HOST_EMULATION
 

@@ -115,6 +115,8 @@ void k_xinv(const cplx* __restrict__ in, const VecBatch vb, int64_t ibatch, doub
     }
 }
 
+// (two 512-thread workgroups of the y passes per CU -- 128 registers, split exchanges, chained twiddle powers, no spills -- change
+// nothing at 512^3: yfwd 2.53 -> 2.51 ms, profiles/r02_experiment_ticketed_half_tiles.log; the passes are bound by their access pattern)
 // A1[Lx][m][l] (natural) -> A2[XB][l][Ly][Lx/XB]
 template <class C, int LINES, bool SPLIT, int WPE, bool EXACT>
 __global__ __launch_bounds__(C::T * LINES, WPE)
@@ -138,7 +140,7 @@ void k_yfwd(const cplx* __restrict__ a1, cplx* __restrict__ a2, const cplx* __re
     for (int e = 0; e < E / 2; ++e) v[e] = (EXACT || t + T * e < m) ? src[(int64_t)p1 * (t + T * e)] : make_double2(0.0, 0.0);
 #pragma unroll
     for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
-    fft_forward<C, LL, true>(v, t, tw, smem, 0, xi);
+    fft_forward<C, LL, true, false, (C::T * LINES > 512)>(v, t, tw, smem, 0, xi);     // (1024-thread workgroups, 128 registers: chained twiddle powers, no spills)
     const int xb = xp / XB, xq = xp % XB;
     cplx* dst = a2 + xq + (int64_t)XB * z + (int64_t)p2 * ((int64_t)Ly * xb);
 #pragma unroll
@@ -166,7 +168,7 @@ void k_yinv(const cplx* __restrict__ a2, cplx* __restrict__ a1, const cplx* __re
     cplx v[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) v[e] = src[(int64_t)p2 * (t + T * e)];
-    fft_inverse<C, LL, true>(v, t, tw, smem, 0, xi);
+    fft_inverse<C, LL, true, false, (C::T * LINES > 512)>(v, t, tw, smem, 0, xi);
     cplx* dst = a1 + xp + (int64_t)p1 * m * z;
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) if (EXACT || t + T * e < m) dst[(int64_t)p1 * (t + T * e)] = v[e];
