@@ -17,6 +17,7 @@
 // < L/2 are wanted) both mean "slots e >= E/2", which lets the first forward /
 // last inverse butterfly drop one radix-2 level (PRUNE).
 #pragma once
+#include <type_traits>
 #ifndef LSFC_FFT_HOST_EMULATION      // tests/emu/ compiles this header with g++ to check the index algebra
 #include <hip/hip_runtime.h>
 #define LSFC_BARRIER() __syncthreads()
@@ -343,6 +344,14 @@ __device__ __forceinline__ void exchange(cplx (&v)[C::E], int t, char* smem, int
         lds_read<C, SB, LL, 2>(v, t, smem, off, xi);  lds_barrier<LOC>();
     }
 }
+// second half of an exchange whose stores were issued by stage<..., LLW>: wait for them, fetch the stage-SB slots
+template <class C, int SB, class LL>
+__device__ __forceinline__ void exchange_read(cplx (&v)[C::E], int t, char* smem, int off, int xi) {
+    static_assert(!LL::SPLIT, "exchange_read: whole-complex layouts only");
+    LSFC_BARRIER();
+    lds_read<C, SB, LL, 2>(v, t, smem, off, xi);
+    LSFC_BARRIER();
+}
 // whether the forward transform ENDS with a wave-local exchange (callers that re-use the exchange buffer right after
 // it, as the fused pass does for the symbol, then need a workgroup barrier of their own)
 template <class C, class LL> constexpr bool forward_ends_local() {
@@ -359,13 +368,20 @@ template <class C, class LL> constexpr bool forward_ends_local() {
 // TWCHAIN (computed twiddles only): the powers w1^q are produced one after the other, w1^q = w1^(q-1) * w1, and applied at once
 // -- two complex numbers live instead of the R of the product tree, at an error of ~q ulp in the q-th power instead of ~4 ulp
 // (3e-15 at radix 16).  For the passes that would otherwise spill (1024-thread workgroups, 128 registers).
-template <class C, int S, int DIR, int PRUNE, bool TWFULL = false, bool TWCHAIN = false>
-__device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __restrict__ tw) {
+// LLW != void (whole-complex layouts): every output also goes to its stage-S position of the exchange buffer as soon as it
+// exists (the first half of exchange<C, S, ., LLW>; finish with exchange_read) -- the 16-byte LDS stores, the slowest LDS
+// operation of the pass, then queue behind the butterflies and twiddle products still being computed instead of after them.
+template <class C, int S, int DIR, int PRUNE, bool TWFULL = false, bool TWCHAIN = false, class LLW = void>
+__device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem = nullptr, int off = 0, int xi = 0) {
     constexpr int LS = C::template LS<S>(), R = C::template R<S>();
     constexpr int M = LS / R, NB = C::E / R;
+    constexpr bool WR = !std::is_void<LLW>::value;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         cplx a[R];
+        [[maybe_unused]] auto put = [&](int q) {
+            if constexpr (WR) reinterpret_cast<cplx*>(smem)[LLW::addr(off, xi, stage_pos<C, S>(t, u + NB * q))] = a[q];
+        };
 #pragma unroll
         for (int q = 0; q < R; ++q) a[q] = v[u + NB * q];
         if constexpr (TWFULL && M > 1) {
@@ -387,13 +403,18 @@ __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __rest
             else if constexpr (PRUNE == 2) dft_halfout<R, DIR>(a);
             else Dft<R, DIR>::run(a);
             if constexpr (DIR > 0) {
+                put(0);
 #pragma unroll
                 for (int q = 1; q < R; ++q) {
                     a[q] = cmul(a[q], tw_at(q));
+                    put(q);
 #ifdef LSFC_TW_CHUNK
                     if (q % LSFC_TW_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
 #endif
                 }
+            } else {
+#pragma unroll
+                for (int q = 0; q < R; ++q) put(q);
             }
         } else if constexpr (TWCHAIN && M > 1) {
             const int r = (t + C::T * u) % M;
@@ -432,6 +453,10 @@ __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __rest
             for (int q = 1; q < R; ++q) a[q] = cmul(a[q], w[q]);
         }
         }
+        if constexpr (WR && !(TWFULL && M > 1)) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) put(q);
+        }
 #pragma unroll
         for (int q = 0; q < R; ++q) v[u + NB * q] = a[q];
     }
@@ -468,6 +493,39 @@ __device__ __forceinline__ void fft_inverse(cplx (&v)[C::E], int t, const cplx* 
     stage<C, 1, -1, 0, TWFULL, TWCHAIN>(v, t, tw);
     exchange<C, 1, 0, LL>(v, t, smem, off, xi);
     stage<C, 0, -1, PRUNE_OUT ? 2 : 0, TWFULL, TWCHAIN>(v, t, tw);
+}
+// The same transforms with the exchange stores issued from inside the stages (stage<..., LL>; whole-complex layouts).
+// `hook` runs between the first stage and the wait for its stores (the fused pass loads its symbol there).
+template <class C, class LL, bool PRUNE_IN, bool TWFULL, class F>
+__device__ __forceinline__ void fft_forward_ws(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi, F&& hook) {
+    stage<C, 0, +1, PRUNE_IN ? 1 : 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
+    hook();
+    exchange_read<C, 1, LL>(v, t, smem, off, xi);
+    if constexpr (C::NS == 2) stage<C, 1, +1, 0, TWFULL>(v, t, tw);
+    else {
+        stage<C, 1, +1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
+        exchange_read<C, 2, LL>(v, t, smem, off, xi);
+        if constexpr (C::NS == 3) stage<C, 2, +1, 0, TWFULL>(v, t, tw);
+        else {
+            stage<C, 2, +1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
+            exchange_read<C, 3, LL>(v, t, smem, off, xi);
+            stage<C, 3, +1, 0, TWFULL>(v, t, tw);
+        }
+    }
+}
+template <class C, class LL, bool PRUNE_OUT, bool TWFULL>
+__device__ __forceinline__ void fft_inverse_ws(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
+    if constexpr (C::NS >= 4) {
+        stage<C, 3, -1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
+        exchange_read<C, 2, LL>(v, t, smem, off, xi);
+    }
+    if constexpr (C::NS >= 3) {
+        stage<C, 2, -1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
+        exchange_read<C, 1, LL>(v, t, smem, off, xi);
+    }
+    stage<C, 1, -1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
+    exchange_read<C, 0, LL>(v, t, smem, off, xi);
+    stage<C, 0, -1, PRUNE_OUT ? 2 : 0, TWFULL>(v, t, tw);
 }
 #endif // !LSFC_FFT_HOST_EMULATION
 

@@ -371,6 +371,11 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
     using LL = LdsLayout<LINES, HALF ? -1 : 3, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = C::T, E = C::E, H = E / 2;
+#ifdef LSFC_NO_STAGE_STORES
+    constexpr bool WS = false;
+#else
+    constexpr bool WS = true;                           // exchange stores from inside the stages (fft_core.hpp: stage<..., LLW>)
+#endif
     const int li = threadIdx.x % LINES, t = threadIdx.x / LINES;
     // work item: a tile (static walk b, b + G, ...) or, HALF, a ticket of this workgroup's XCD
     // (HALF: a work item is (ticket << 3 | queue); DONE = nothing left anywhere)
@@ -445,7 +450,11 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
             for (int e = 0; e < H; ++e) sv[e] = s[so + sstep * e];
             if (t == 0) smid = s[so - (unsigned)((int)sLine * t) + (unsigned)((int)sLine * (C::L / 2))];
         };
-        if constexpr (LATE_SYM) {
+        if constexpr (!SPLIT && WS) {
+            // exchange stores issued from inside the stages (fft_forward_ws); the symbol is loaded after the first stage
+            if constexpr (!LATE_SYM) load_symbol();
+            fft_forward_ws<C, LL, true, TWL>(v, t, tw, smem, 0, li, [&] { if constexpr (LATE_SYM) load_symbol(); });
+        } else if constexpr (LATE_SYM) {
             // the first forward stage (the widest butterfly plus its twiddles) runs before the symbol values occupy registers
             stage<C, 0, +1, 1, TWL>(v, t, tw);
             load_symbol();
@@ -484,7 +493,8 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
 #pragma unroll
             for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? dn[dof + dstep * e] : make_double2(0.0, 0.0);
         }
-        fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+        if constexpr (!SPLIT && WS) fft_inverse_ws<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+        else fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         {
             cplx* d; const cplx* s;
             locate(cur, d, s);
