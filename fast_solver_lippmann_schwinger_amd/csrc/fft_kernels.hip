@@ -232,6 +232,15 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
         __syncthreads();
         tw = tl;
     }
+    // (whole-complex layouts: exchange stores issued from inside the stages, fft_core.hpp)
+    auto fwd = [&](cplx (&w)[E]) {
+        if constexpr (!SPLIT) fft_forward_ws<C, LL, true, TWL>(w, t, tw, smem, 0, li, [] {});
+        else fft_forward<C, LL, true, TWL>(w, t, tw, smem, 0, li);
+    };
+    auto inv = [&](cplx (&w)[E]) {
+        if constexpr (!SPLIT) fft_inverse_ws<C, LL, true, TWL>(w, t, tw, smem, 0, li);
+        else fft_inverse<C, LL, true, TWL>(w, t, tw, smem, 0, li);
+    };
     cplx v[E];
     if constexpr (MULTI) {
         // symbol tile once, then every right-hand side of the batch
@@ -252,7 +261,7 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
             for (int e = 0; e < E / 2; ++e) v[e] = (EXACT || t + T * e < nin) ? dr[dLine * (t + T * e)] : make_double2(0.0, 0.0);
 #pragma unroll
             for (int e = E / 2; e < E; ++e) v[e] = make_double2(0.0, 0.0);
-            fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+            fwd(v);
             if constexpr (ZE) {
                 cplx* stage = reinterpret_cast<cplx*>(smem);
                 if constexpr (forward_ends_local<C, LL>()) LSFC_BARRIER();   // other waves may still read the exchange buffer
@@ -270,7 +279,7 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
 #pragma unroll
                 for (int e = 0; e < E; ++e) v[e] = cmul(v[e], sv[e]);
             }
-            fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+            inv(v);
 #pragma unroll
             for (int e = 0; e < E / 2; ++e) if (EXACT || t + T * e < nin) dr[dLine * (t + T * e)] = v[e];
             // (every exchange ends with a barrier after its reads: the buffer is free for the next member)
@@ -291,7 +300,7 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
 #pragma unroll
             for (int e = 0; e < H; ++e) sv[e] = s[sLine * (t + T * e)];
         }
-        fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+        fwd(v);
         if constexpr (!PREFETCH) {
 #pragma unroll
             for (int e = 0; e < H; ++e) sv[e] = s[sLine * (t + T * e)];
@@ -314,15 +323,15 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
         cplx sv[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) sv[e] = s[sLine * (t + T * e)];
-        fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+        fwd(v);
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = cmul(v[e], sv[e]);
     } else {
-        fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+        fwd(v);
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = cmul(v[e], s[sLine * (t + T * e)]);
     }
-    fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+    inv(v);
 #pragma unroll
     for (int e = 0; e < E / 2; ++e) if (EXACT || t + T * e < nin) d[dLine * (t + T * e)] = v[e];
 }
