@@ -345,12 +345,13 @@ __device__ __forceinline__ void exchange(cplx (&v)[C::E], int t, char* smem, int
     }
 }
 // second half of an exchange whose stores were issued by stage<..., LLW>: wait for them, fetch the stage-SB slots
-template <class C, int SB, class LL>
+// TRAIL = false: the caller frees the buffer itself before anything is stored into it again (stage<..., BARF>, or a barrier)
+template <class C, int SB, class LL, bool TRAIL = true>
 __device__ __forceinline__ void exchange_read(cplx (&v)[C::E], int t, char* smem, int off, int xi) {
     static_assert(!LL::SPLIT, "exchange_read: whole-complex layouts only");
     LSFC_BARRIER();
     lds_read<C, SB, LL, 2>(v, t, smem, off, xi);
-    LSFC_BARRIER();
+    if constexpr (TRAIL) LSFC_BARRIER();
 }
 // whether the forward transform ENDS with a wave-local exchange (callers that re-use the exchange buffer right after
 // it, as the fused pass does for the symbol, then need a workgroup barrier of their own)
@@ -371,16 +372,24 @@ template <class C, class LL> constexpr bool forward_ends_local() {
 // LLW != void (whole-complex layouts): every output also goes to its stage-S position of the exchange buffer as soon as it
 // exists (the first half of exchange<C, S, ., LLW>; finish with exchange_read) -- the 16-byte LDS stores, the slowest LDS
 // operation of the pass, then queue behind the butterflies and twiddle products still being computed instead of after them.
-template <class C, int S, int DIR, int PRUNE, bool TWFULL = false, bool TWCHAIN = false, class LLW = void>
+// BARF: the workgroup barrier that frees the exchange buffer (every wave has finished the loads of the previous exchange) is
+// taken here, just before the stage's FIRST store, instead of right after those loads: the first butterfly of every wave runs
+// while the slower waves are still loading.  (__syncthreads drains the wave's own LDS queue first, so all of its loads of the
+// previous exchange -- also those for its later butterflies -- have completed when it passes.)
+template <class C, int S, int DIR, int PRUNE, bool TWFULL = false, bool TWCHAIN = false, class LLW = void, bool BARF = false>
 __device__ __forceinline__ void stage(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem = nullptr, int off = 0, int xi = 0) {
     constexpr int LS = C::template LS<S>(), R = C::template R<S>();
     constexpr int M = LS / R, NB = C::E / R;
     constexpr bool WR = !std::is_void<LLW>::value;
+    [[maybe_unused]] bool first = true;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         cplx a[R];
         [[maybe_unused]] auto put = [&](int q) {
-            if constexpr (WR) reinterpret_cast<cplx*>(smem)[LLW::addr(off, xi, stage_pos<C, S>(t, u + NB * q))] = a[q];
+            if constexpr (WR) {
+                if constexpr (BARF) { if (first) { LSFC_BARRIER(); first = false; } }
+                reinterpret_cast<cplx*>(smem)[LLW::addr(off, xi, stage_pos<C, S>(t, u + NB * q))] = a[q];
+            }
         };
 #pragma unroll
         for (int q = 0; q < R; ++q) a[q] = v[u + NB * q];
@@ -496,35 +505,39 @@ __device__ __forceinline__ void fft_inverse(cplx (&v)[C::E], int t, const cplx* 
 }
 // The same transforms with the exchange stores issued from inside the stages (stage<..., LL>; whole-complex layouts).
 // `hook` runs between the first stage and the wait for its stores (the fused pass loads its symbol there).
-template <class C, class LL, bool PRUNE_IN, bool TWFULL, class F>
+// DEFER: the barriers that free the exchange buffer are taken inside the following stage, before its first store (BARF), and
+// by the CALLER after the last forward stage (before it stores into the buffer) and before the first stage of the next
+// forward transform (a stage with BARF, or a barrier).
+template <class C, class LL, bool PRUNE_IN, bool TWFULL, bool DEFER = false, class F>
 __device__ __forceinline__ void fft_forward_ws(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi, F&& hook) {
-    stage<C, 0, +1, PRUNE_IN ? 1 : 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
+    stage<C, 0, +1, PRUNE_IN ? 1 : 0, TWFULL, false, LL, DEFER>(v, t, tw, smem, off, xi);
     hook();
-    exchange_read<C, 1, LL>(v, t, smem, off, xi);
+    exchange_read<C, 1, LL, !DEFER>(v, t, smem, off, xi);
     if constexpr (C::NS == 2) stage<C, 1, +1, 0, TWFULL>(v, t, tw);
     else {
-        stage<C, 1, +1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
-        exchange_read<C, 2, LL>(v, t, smem, off, xi);
+        stage<C, 1, +1, 0, TWFULL, false, LL, DEFER>(v, t, tw, smem, off, xi);
+        exchange_read<C, 2, LL, !DEFER>(v, t, smem, off, xi);
         if constexpr (C::NS == 3) stage<C, 2, +1, 0, TWFULL>(v, t, tw);
         else {
-            stage<C, 2, +1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
-            exchange_read<C, 3, LL>(v, t, smem, off, xi);
+            stage<C, 2, +1, 0, TWFULL, false, LL, DEFER>(v, t, tw, smem, off, xi);
+            exchange_read<C, 3, LL, !DEFER>(v, t, smem, off, xi);
             stage<C, 3, +1, 0, TWFULL>(v, t, tw);
         }
     }
 }
-template <class C, class LL, bool PRUNE_OUT, bool TWFULL>
+template <class C, class LL, bool PRUNE_OUT, bool TWFULL, bool DEFER = false>
 __device__ __forceinline__ void fft_inverse_ws(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
+    // (the caller has synchronised after its own use of the buffer: the first stage stores at once)
     if constexpr (C::NS >= 4) {
         stage<C, 3, -1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
-        exchange_read<C, 2, LL>(v, t, smem, off, xi);
+        exchange_read<C, 2, LL, !DEFER>(v, t, smem, off, xi);
     }
     if constexpr (C::NS >= 3) {
-        stage<C, 2, -1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
-        exchange_read<C, 1, LL>(v, t, smem, off, xi);
+        stage<C, 2, -1, 0, TWFULL, false, LL, (DEFER && C::NS >= 4)>(v, t, tw, smem, off, xi);
+        exchange_read<C, 1, LL, !DEFER>(v, t, smem, off, xi);
     }
-    stage<C, 1, -1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
-    exchange_read<C, 0, LL>(v, t, smem, off, xi);
+    stage<C, 1, -1, 0, TWFULL, false, LL, (DEFER && C::NS >= 3)>(v, t, tw, smem, off, xi);
+    exchange_read<C, 0, LL, !DEFER>(v, t, smem, off, xi);
     stage<C, 0, -1, PRUNE_OUT ? 2 : 0, TWFULL>(v, t, tw);
 }
 #endif // !LSFC_FFT_HOST_EMULATION

@@ -385,6 +385,14 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
 #else
     constexpr bool WS = true;                           // exchange stores from inside the stages (fft_core.hpp: stage<..., LLW>)
 #endif
+    // ... with the buffer-freeing barriers taken inside the next stage, before its first store (BARF), instead of right after the
+    // loads: measured SLOWER (same-box A/B 4.88 -> 5.06 ms: the barrier then separates a wave's butterflies from its own stores);
+    // off, kept for A/B builds (make EXTRA=-DLSFC_DEFERRED_BARRIERS)
+#ifdef LSFC_DEFERRED_BARRIERS
+    constexpr bool DEFER = true;
+#else
+    constexpr bool DEFER = false;
+#endif
     const int li = threadIdx.x % LINES, t = threadIdx.x / LINES;
     // work item: a tile (static walk b, b + G, ...) or, HALF, a ticket of this workgroup's XCD
     // (HALF: a work item is (ticket << 3 | queue); DONE = nothing left anywhere)
@@ -462,7 +470,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         if constexpr (!SPLIT && WS) {
             // exchange stores issued from inside the stages (fft_forward_ws); the symbol is loaded after the first stage
             if constexpr (!LATE_SYM) load_symbol();
-            fft_forward_ws<C, LL, true, TWL>(v, t, tw, smem, 0, li, [&] { if constexpr (LATE_SYM) load_symbol(); });
+            fft_forward_ws<C, LL, true, TWL, DEFER>(v, t, tw, smem, 0, li, [&] { if constexpr (LATE_SYM) load_symbol(); });
         } else if constexpr (LATE_SYM) {
             // the first forward stage (the widest butterfly plus its twiddles) runs before the symbol values occupy registers
             stage<C, 0, +1, 1, TWL>(v, t, tw);
@@ -476,7 +484,8 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
             fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         }
         cplx* stage = reinterpret_cast<cplx*>(smem);
-        if constexpr (forward_ends_local<C, LL>()) LSFC_BARRIER();   // other waves may still read the exchange buffer
+        // other waves may still read the exchange buffer (wave-local last exchange, or the deferred barrier of fft_forward_ws)
+        if constexpr (forward_ends_local<C, LL>() || (!SPLIT && WS && DEFER)) LSFC_BARRIER();
 #pragma unroll
         for (int e = 0; e < H; ++e) stage[(t + T * e) * LINES + li] = sv[e];
         if (t == 0) stage[(C::L / 2) * LINES + li] = smid;
@@ -502,7 +511,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
 #pragma unroll
             for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? dn[dof + dstep * e] : make_double2(0.0, 0.0);
         }
-        if constexpr (!SPLIT && WS) fft_inverse_ws<C, LL, true, TWL>(v, t, tw, smem, 0, li);
+        if constexpr (!SPLIT && WS) fft_inverse_ws<C, LL, true, TWL, DEFER>(v, t, tw, smem, 0, li);
         else fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         {
             cplx* d; const cplx* s;
