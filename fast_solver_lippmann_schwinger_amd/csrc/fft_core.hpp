@@ -21,6 +21,8 @@
 #ifndef LSFC_FFT_HOST_EMULATION      // tests/emu/ compiles this header with g++ to check the index algebra
 #include <hip/hip_runtime.h>
 #define LSFC_BARRIER() __syncthreads()
+#else
+#define LSFC_BARRIER() ((void)0)     // (the emulator runs one thread at a time and synchronises in its own driver loop)
 #endif
 #include <utility>
 
