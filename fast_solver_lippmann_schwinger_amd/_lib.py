@@ -72,6 +72,8 @@ SIGNATURES = {
     "lsfc_free": (_I, [_P]),
     "lsfc_memcpy_h2d": (_I, [_P, _P, C.c_size_t]),
     "lsfc_memcpy_d2h": (_I, [_P, _P, C.c_size_t]),
+    "lsfc_host_register": (_I, [_P, C.c_size_t]),
+    "lsfc_host_unregister": (_I, [_P]),
     "lsfc_dist_unique_id": (_I, [_P]),
     "lsfc_dist_plan_create_gv3d": (_I, [_PP, _L, _L, _L, _D, _D, _P, _U, _I, _I, _I, _P]),
     "lsfc_dist_sim_plan_create_gv3d": (_I, [_PP, _L, _L, _L, _D, _D, _P, _U, _I, _I, _I]),
@@ -112,6 +114,15 @@ def check(rc):
     if rc != 0:
         raise LsfcError(rc, load().lsfc_last_error().decode(errors="replace"))
     return rc
+
+
+def host_register(a):
+    """Page-lock a long-lived numpy vector (lsfc_host_register): host-vector applies then move it by DMA."""
+    check(load().lsfc_host_register(a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+
+def host_unregister(a):
+    check(load().lsfc_host_unregister(a.ctypes.data_as(C.c_void_p)))
 
 
 def device_count():

@@ -364,6 +364,73 @@ template <class C, class LL> constexpr bool forward_ends_local() {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------
+// Exchange between the last two stages THROUGH THE LANES of a wavefront instead of LDS (round 3).
+// When both stages have radix 8 (16.8.8, 24.8.8, 8.8.8) the exchange between them is, for every u, the 8 x 8 transpose
+//     slot (u, q) of thread t   ->   slot (u, t & 7) of thread (t & ~7) | q
+// (stage_pos<C, S>(t, u + NB q) = 64 (b / 8) + (b & 7) + 8 q  ==  stage_pos<C, S + 1>(t', u + NB q') = 8 b' + q' with
+// b = t + T u: b' = 8 (b / 8) + q, q' = b & 7; checked for every factorisation by tests/emu).  In the interleaved passes
+// lane = line + LSTR * t, so the eight threads of a transpose sit in ONE wavefront at lane bits LB .. LB + 2 (LB = 3 for 8
+// interleaved lines, 2 for 4) and the transpose is three butterfly steps, step k swapping the slots (q, q | 2^k) between
+// the lanes that differ in bit LB + k.  gfx950 swaps across lane bit 5 / 4 with one v_permlane32_swap / v_permlane16_swap
+// per dword pair, across bit 3 with two DPP moves (row_ror:8 under complementary bank masks) and across bit 2 with
+// row_shr:4 / row_shl:4.  Per 16-byte element that is 2 + 2 + 4 VALU operations against one ds_write_b128 (13 cycles of the
+// CU's LDS store path, the slowest LDS operation of the fused pass) + one ds_read_b128, and two workgroup barriers go.
+#ifndef LSFC_FFT_HOST_EMULATION
+template <int BIT> __device__ __forceinline__ void xlane_step32(unsigned& a, unsigned& b) {
+    // lanes with bit BIT clear keep a and take the partner's a into b; lanes with the bit set keep b and take the
+    // partner's b into a (partner = lane ^ (1 << BIT))
+    if constexpr (BIT == 5) { const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r[0]; b = r[1]; }
+    else if constexpr (BIT == 4) { const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r[0]; b = r[1]; }
+    else if constexpr (BIT == 3) {
+        // row_ror:8 = lane ^ 8 inside a row of 16; bank_mask 0xc: lanes 8..15 of the row are written, 0x3: lanes 0..7
+        const unsigned na = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x128, 0xf, 0xc, false);
+        const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x128, 0xf, 0x3, false);
+        a = na; b = nb;
+    } else {
+        static_assert(BIT == 2, "xlane_step32: lane bits 2..5");
+        // row_shr:4 (lane i takes lane i - 4) into the lanes with bit 2 set (banks 1, 3); row_shl:4 into the others
+        const unsigned na = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x114, 0xf, 0xa, false);
+        const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x104, 0xf, 0x5, false);
+        a = na; b = nb;
+    }
+}
+template <int BIT> __device__ __forceinline__ void xlane_step(cplx& a, cplx& b) {
+    unsigned a0 = (unsigned)__double2loint(a.x), a1 = (unsigned)__double2hiint(a.x), a2 = (unsigned)__double2loint(a.y), a3 = (unsigned)__double2hiint(a.y);
+    unsigned b0 = (unsigned)__double2loint(b.x), b1 = (unsigned)__double2hiint(b.x), b2 = (unsigned)__double2loint(b.y), b3 = (unsigned)__double2hiint(b.y);
+    xlane_step32<BIT>(a0, b0); xlane_step32<BIT>(a1, b1); xlane_step32<BIT>(a2, b2); xlane_step32<BIT>(a3, b3);
+    a = make_double2(__hiloint2double((int)a1, (int)a0), __hiloint2double((int)a3, (int)a2));
+    b = make_double2(__hiloint2double((int)b1, (int)b0), __hiloint2double((int)b3, (int)b2));
+}
+#endif
+// the exchange between the last two stages of C can run through the lanes of layout LL
+template <class C, class LL> constexpr bool xlane_ok() {
+    if constexpr (C::NS != 3) return false;
+    else return C::R1 == 8 && C::R2 == 8 && C::template LS<2>() == 8 && C::T % 8 == 0 && C::E % 8 == 0 && (LL::LSTR == 8 || LL::LSTR == 4) && !LL::SPLIT;
+}
+// the three butterfly steps, written over a primitive STEP(bit, a, b) so that tests/emu can run the same schedule on an
+// emulated wavefront
+template <class C, int LSTR, class STEP> __device__ __forceinline__ void xlane_transpose8_with(cplx (&v)[C::E], STEP&& step) {
+    constexpr int NB = C::E / 8;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (!((q >> k) & 1)) step(k, v[u + NB * q], v[u + NB * (q | (1 << k))]);
+        }
+    }
+}
+#ifndef LSFC_FFT_HOST_EMULATION
+template <class C, int LSTR> __device__ __forceinline__ void xlane_transpose8(cplx (&v)[C::E]) {
+    constexpr int LB = LSTR == 8 ? 3 : 2;
+    xlane_transpose8_with<C, LSTR>(v, [](int k, cplx& a, cplx& b) __attribute__((always_inline)) {
+        if (k == 0) xlane_step<LB>(a, b); else if (k == 1) xlane_step<LB + 1>(a, b); else xlane_step<LB + 2>(a, b);
+    });
+}
+#endif
+
 // One butterfly stage on the register slots.  PRUNE: 0 full; 1 forward with inputs
 // q >= R/2 zero; 2 inverse with only outputs q < R/2 wanted.
 // TWFULL: `tw` is the full stage-twiddle table (Cfg::TWOFF layout, normally staged in LDS): every power is read,
@@ -510,13 +577,19 @@ __device__ __forceinline__ void fft_inverse(cplx (&v)[C::E], int t, const cplx* 
 // DEFER: the barriers that free the exchange buffer are taken inside the following stage, before its first store (BARF), and
 // by the CALLER after the last forward stage (before it stores into the buffer) and before the first stage of the next
 // forward transform (a stage with BARF, or a barrier).
-template <class C, class LL, bool PRUNE_IN, bool TWFULL, bool DEFER = false, class F>
+// XL: the exchange between the last two (radix-8) stages runs through the lanes (xlane_transpose8), not LDS.
+template <class C, class LL, bool PRUNE_IN, bool TWFULL, bool DEFER = false, bool XL = false, class F>
 __device__ __forceinline__ void fft_forward_ws(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi, F&& hook) {
+    static_assert(!XL || (xlane_ok<C, LL>() && !DEFER), "fft_forward_ws: lane exchange not available for this line / layout");
     stage<C, 0, +1, PRUNE_IN ? 1 : 0, TWFULL, false, LL, DEFER>(v, t, tw, smem, off, xi);
     hook();
     exchange_read<C, 1, LL, !DEFER>(v, t, smem, off, xi);
     if constexpr (C::NS == 2) stage<C, 1, +1, 0, TWFULL>(v, t, tw);
-    else {
+    else if constexpr (XL) {
+        stage<C, 1, +1, 0, TWFULL>(v, t, tw);
+        xlane_transpose8<C, LL::LSTR>(v);
+        stage<C, 2, +1, 0, TWFULL>(v, t, tw);
+    } else {
         stage<C, 1, +1, 0, TWFULL, false, LL, DEFER>(v, t, tw, smem, off, xi);
         exchange_read<C, 2, LL, !DEFER>(v, t, smem, off, xi);
         if constexpr (C::NS == 3) stage<C, 2, +1, 0, TWFULL>(v, t, tw);
@@ -527,9 +600,14 @@ __device__ __forceinline__ void fft_forward_ws(cplx (&v)[C::E], int t, const cpl
         }
     }
 }
-template <class C, class LL, bool PRUNE_OUT, bool TWFULL, bool DEFER = false>
+template <class C, class LL, bool PRUNE_OUT, bool TWFULL, bool DEFER = false, bool XL = false>
 __device__ __forceinline__ void fft_inverse_ws(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
+    static_assert(!XL || (xlane_ok<C, LL>() && !DEFER), "fft_inverse_ws: lane exchange not available for this line / layout");
     // (the caller has synchronised after its own use of the buffer: the first stage stores at once)
+    if constexpr (XL) {
+        stage<C, 2, -1, 0, TWFULL>(v, t, tw);
+        xlane_transpose8<C, LL::LSTR>(v);
+    } else {
     if constexpr (C::NS >= 4) {
         stage<C, 3, -1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
         exchange_read<C, 2, LL, !DEFER>(v, t, smem, off, xi);
@@ -538,11 +616,23 @@ __device__ __forceinline__ void fft_inverse_ws(cplx (&v)[C::E], int t, const cpl
         stage<C, 2, -1, 0, TWFULL, false, LL, (DEFER && C::NS >= 4)>(v, t, tw, smem, off, xi);
         exchange_read<C, 1, LL, !DEFER>(v, t, smem, off, xi);
     }
+    }
     stage<C, 1, -1, 0, TWFULL, false, LL, (DEFER && C::NS >= 3)>(v, t, tw, smem, off, xi);
     exchange_read<C, 0, LL, !DEFER>(v, t, smem, off, xi);
     stage<C, 0, -1, PRUNE_OUT ? 2 : 0, TWFULL>(v, t, tw);
 }
 #endif // !LSFC_FFT_HOST_EMULATION
+
+// Work items of the ticketed fused pass (fft_kernels.hip: k_zfused_persist): w = (ticket c << 3) | queue q, q = 0..7 (one
+// queue per XCD), c = 0 .. nwork - 1 with nwork = ntiles / 8 whole tiles or ntiles / 4 half tiles per queue (ntiles a
+// multiple of 16).  Whole tiles: ticket c of queue q is tile 2 (q + 8 (c >> 1)) + (c & 1) -- two consecutive tickets are
+// two tiles next to each other in block order, i.e. (y-even symbol) a row and its mirror row, which read the same symbol
+// rows.  Half tiles: ticket c is half c & 1 of tile 2 (q + 8 (c >> 2)) + ((c >> 1) & 1) -- four consecutive tickets are
+// the halves of such a pair.  Every (tile, half) is handed out exactly once over the eight queues (tests/emu).
+template <bool HALF> __device__ __forceinline__ void ticket_decode(unsigned w, unsigned& tile, unsigned& half) {
+    if constexpr (HALF) { tile = 2u * ((w & 7u) + 8u * (w >> 5)) + ((w >> 4) & 1u); half = (w >> 3) & 1u; }
+    else { tile = 2u * ((w & 7u) + 8u * (w >> 4)) + ((w >> 3) & 1u); half = 0u; }
+}
 
 // Host mirror of the slot bookkeeping: frequency index held at storage index s.
 // After the last stage slot e = u + NB*q of thread t sits at position (t + T*u)*RL + q; in-place DIF leaves

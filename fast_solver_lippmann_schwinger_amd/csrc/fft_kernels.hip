@@ -372,7 +372,9 @@ template <class C, int LINES, bool SPLIT, bool TWL, bool HALF> constexpr size_t 
     return (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes() + (TWL ? (size_t)C::TWLEN * sizeof(cplx) : 0);
 }
 // TICKETS without HALF: whole tiles handed out the same way, in pairs (row, mirror row) per XCD queue.
-template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL, bool LATE_SYM = false, bool HALF = false, bool TICKETS = HALF>
+// XL: the exchange between the two radix-8 stages of the line runs through the lanes of the wavefront (fft_core.hpp:
+// xlane_transpose8) instead of LDS -- one LDS exchange and two workgroup barriers less per direction.
+template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL, bool LATE_SYM = false, bool HALF = false, bool TICKETS = HALF, bool XL = false>
 __global__ __launch_bounds__(C::T * LINES, (HALF && 2 * persist_lds_bytes<C, LINES, SPLIT, TWL, HALF>() <= (size_t)160 * 1024) ? 2 : 1)
 void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
                       int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
@@ -430,10 +432,8 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
     // share the in-order vmcnt counter).
     auto locate = [&](unsigned w, cplx*& dbase, const cplx*& sbase) {
         unsigned tl_ = w; int half = 0;
-        // ticket c = w >> 3 of queue q = w & 7: half c & 1 of tile 2 (q + 8 (c >> 2)) + ((c >> 1) & 1) -- four consecutive tickets
-        // are the halves of two tiles next to each other in block order, i.e. (y-even symbol) of a row and its mirror
-        if constexpr (HALF) { tl_ = 2u * ((w & 7u) + 8u * (w >> 5)) + ((w >> 4) & 1u); half = (int)((w >> 3) & 1u) * LINES; }
-        else if constexpr (TICKETS) { tl_ = 2u * ((w & 7u) + 8u * (w >> 4)) + ((w >> 3) & 1u); }
+        // (ticket -> tile, half: fft_core.hpp ticket_decode)
+        if constexpr (TICKETS) { unsigned hf; ticket_decode<HALF>(w, tl_, hf); half = (int)hf * LINES; }
         const int o = (int)(tl_ % (unsigned)nouter), g = (int)(tl_ / (unsigned)nouter);
         int outer = o, srow = o;
         if (ytab) { const int2 e2 = ytab[o]; outer = e2.x; srow = e2.y; }
@@ -470,7 +470,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         if constexpr (!SPLIT && WS) {
             // exchange stores issued from inside the stages (fft_forward_ws); the symbol is loaded after the first stage
             if constexpr (!LATE_SYM) load_symbol();
-            fft_forward_ws<C, LL, true, TWL, DEFER>(v, t, tw, smem, 0, li, [&] { if constexpr (LATE_SYM) load_symbol(); });
+            fft_forward_ws<C, LL, true, TWL, DEFER, XL>(v, t, tw, smem, 0, li, [&] { if constexpr (LATE_SYM) load_symbol(); });
         } else if constexpr (LATE_SYM) {
             // the first forward stage (the widest butterfly plus its twiddles) runs before the symbol values occupy registers
             stage<C, 0, +1, 1, TWL>(v, t, tw);
@@ -511,7 +511,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
 #pragma unroll
             for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? dn[dof + dstep * e] : make_double2(0.0, 0.0);
         }
-        if constexpr (!SPLIT && WS) fft_inverse_ws<C, LL, true, TWL, DEFER>(v, t, tw, smem, 0, li);
+        if constexpr (!SPLIT && WS) fft_inverse_ws<C, LL, true, TWL, DEFER, XL>(v, t, tw, smem, 0, li);
         else fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         {
             cplx* d; const cplx* s;
@@ -648,7 +648,7 @@ static int cu_count() {
 static unsigned* ticket_set(hipStream_t st);
 template <class C, bool SPLIT, bool LATE_SYM = false, bool TICKETS = false> static void zfused_persist_t(cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                                                             int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                                                            const int2* ytab, const int* zm, int nin, hipStream_t st) {
+                                                            const int2* ytab, const int* zm, int nin, hipStream_t st, bool xl = false) {
     constexpr int LINES = XB;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
@@ -658,6 +658,13 @@ template <class C, bool SPLIT, bool LATE_SYM = false, bool TICKETS = false> stat
         k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS>;
         lds += (size_t)C::TWLEN * sizeof(cplx);
         tw = twl;
+    }
+    // lane exchange between the two radix-8 stages (ticketed whole tiles, symbol after the first stage: the 512^3 form)
+    if constexpr (xlane_ok<C, LL>() && LATE_SYM && TICKETS) {
+        if (xl) {
+            if (twl) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, true> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, true>;
+            else     k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false, LATE_SYM, false, TICKETS, true> : k_zfused_persist<C, LINES, SPLIT, false, false, LATE_SYM, false, TICKETS, true>;
+        }
     }
     if (TICKETS) lds += 16;                             // the ticket slot
     allow_lds(k, lds);
@@ -693,12 +700,15 @@ static unsigned* ticket_set(hipStream_t st) {
 // the same on half tiles: 4-line workgroups with the twiddle table, as many per CU as the LDS holds (two at L = 1024)
 template <class C> static void zfused_persist_half_t(cplx* data, const cplx* sym, const cplx* twl, int Lx, int nouter,
                                                      int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                                                     const int2* ytab, const int* zm, int nin, hipStream_t st) {
+                                                     const int2* ytab, const int* zm, int nin, hipStream_t st, bool xl = false) {
     if constexpr (C::L >= 1024) {
         constexpr int LINES = XB / 2;
         constexpr size_t lds = persist_lds_bytes<C, LINES, false, true, true>() + 16;   // + the ticket slot
         static_assert(lds <= (size_t)160 * 1024, "half-tile persistent pass: exchange buffer exceeds the LDS");
         auto k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, false, true, true, true, true> : k_zfused_persist<C, LINES, false, false, true, true, true>;
+        if constexpr (xlane_ok<C, LdsLayout<LINES, -1, false>>()) {
+            if (xl) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, false, true, true, true, true, true, true> : k_zfused_persist<C, LINES, false, false, true, true, true, true, true>;
+        }
         LSFC_REQUIRE(twl != nullptr, "half-tile persistent pass: twiddle table missing");
         allow_lds(k, lds);
         const unsigned ntiles = (unsigned)((Lx / XB) * nouter);
@@ -847,13 +857,13 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
             const bool split = zp == 2 || zp == 4 || full_lds > (size_t)160 * 1024;
             // 5: half tiles (4-line workgroups, swizzled unpadded exchange buffer + twiddle table), two workgroups per CU at L = 1024
             if (half5) {
-                LSFC_DISPATCH_L(L, (zfused_persist_half_t<C>(data, sym, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st)));
+                LSFC_DISPATCH_L(L, (zfused_persist_half_t<C>(data, sym, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, tn.xlane != 0)));
                 LSFC_HIP(hipGetLastError());
                 return;
             }
             // 6: whole tiles (as 3) handed out by tickets in row pairs per XCD
             if (zp == 6 && !split && ((int64_t)(Lx / XB) * nouter) % 16 == 0 && nouter % 2 == 0) {
-                LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st)));
+                LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, tn.xlane != 0)));
                 LSFC_HIP(hipGetLastError());
                 return;
             }
@@ -943,8 +953,9 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
     bool sp = tn.split_z >= 0 ? tn.split_z != 0 : !full;
     const bool pf = tn.sym_prefetch >= 0 ? tn.sym_prefetch != 0 : e16;
     // whole-complex exchange buffers of the longest lines exceed the 160 KiB of LDS: those run split
+    // (sized by the workgroup zfused_t launches: Tune<C>::LINES lines -- the y passes alone use YLINES)
     size_t full_lds = 0;
-    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::YLINES, 3, false>::line_elems(C::L) * Tune<C>::YLINES * 16));
+    LSFC_DISPATCH_L(L, (full_lds = (size_t)LdsLayout<Tune<C>::LINES, 3, false>::line_elems(C::L) * Tune<C>::LINES * 16));
     if (full_lds > (size_t)160 * 1024) sp = true;
     if (sp) { if (pf) { LSFC_ZF(true, true); } else { LSFC_ZF(true, false); } }
     else    { if (pf) { LSFC_ZF(false, true); } else { LSFC_ZF(false, false); } }

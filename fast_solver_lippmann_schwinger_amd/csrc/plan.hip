@@ -296,7 +296,9 @@ void plan_finish_symbol(lsfc_plan* p, DevBuf<cplx>& G2, bool quarter) {
                 // pass's situation (same kernels, same z-even symbol layout), instead of 64-B pieces a whole row apart.
                 const char* t2 = getenv("LSFC_2D_TILED");
                 const bool tiled = t2 ? t2[0] == '1' : Ly >= 2048;      // (at 1024 points the 8-line tiles are too few for the chip: 128 workgroups)
-                if (tiled && p->pads[0] % 8 == 0 && p->pads[0] <= 2048) {
+                // (the tiled fused pass is the 3D half-tile kernel: whole groups of 8 tiles -- Lx / 8 tiles here; a short x axis,
+                // e.g. n = 80 next to m = 1024, keeps the natural rows)
+                if (tiled && p->pads[0] % 8 == 0 && (p->pads[0] / 8) % 8 == 0 && p->pads[0] <= 2048) {
                     p->sym_hz = Ly / 2 + 8; p->sym_rows = 1;
                     DevBuf<int> zero; zero.alloc(1);
                     LSFC_HIP(hipMemset(zero.p, 0, sizeof(int)));
@@ -477,6 +479,81 @@ static void ensure_staging(lsfc_plan* p, int64_t count) {
     if (p->xs.n < (size_t)count) { p->xs.alloc((size_t)count); p->ys.alloc((size_t)count); }
 }
 
+HostPipe::~HostPipe() {
+    for (hipEvent_t e : ev_up) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_down) (void)hipEventDestroy(e);
+    if (ev_free) (void)hipEventDestroy(ev_free);
+    if (up) (void)hipStreamDestroy(up);
+    if (down) (void)hipStreamDestroy(down);
+}
+
+// The drop-in path the reference exercises, mul!(Y, M, b) with HOST vectors (src/FastConvolution.jl:50-54), as a pipeline over
+// K chunks of z planes: chunk c of x travels host -> device on its own stream while the x and y passes of the chunks already
+// landed run (those passes work plane by plane: yfwd of plane z needs xfwd of plane z only); then the fused z pass, which needs
+// every plane; then the inverse y and x passes chunk by chunk, each chunk of y leaving for the host as soon as it exists.
+// What cannot overlap: the first byte of y depends on the last byte of x (the Green's kernel is dense), so the upload and
+// the download of ONE apply are strictly one after the other -- the floor is 2 N 16 B / PCIe rate + the fused pass
+// (512^3: 2 x 37.5 ms at the 57 GB/s this box moves per direction + 4.7 ms), not the full-duplex rate.
+// Caller memory: pageable vectors go through the runtime's staged copies (measured 56 / 50 GB/s up / down, no slower than
+// pinned on this box); vectors registered with lsfc_host_register (or allocated pinned) are read and written by DMA directly.
+static int host_pipeline_chunks(const lsfc_plan* p) {
+    const char* e = getenv("LSFC_HOST_PIPELINE");                  // developer switch: 0 / 1 off, K >= 2 chunks whatever the size
+    const int forced = e ? atoi(e) : -1;
+    if (forced == 0 || forced == 1) return 1;
+    if (p->pipeline != lsfc_plan::PRUNED || p->ndim != 3 || p->dist || p->multi) return 1;
+    if (forced < 0 && p->N * (int64_t)sizeof(cplx) < ((int64_t)64 << 20)) return 1;       // small vectors: one copy each way
+    const int l = p->dims[2];
+    for (int K = forced > 1 ? forced : 8; K >= 2; --K) if (l % K == 0) return K;
+    return 1;
+}
+
+static void host_pipelined_convolve(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta, int K) {
+    if (!p->hostpipe) {
+        std::unique_ptr<HostPipe> hp(new HostPipe());
+        LSFC_HIP(hipStreamCreateWithFlags(&hp->up, hipStreamNonBlocking));
+        LSFC_HIP(hipStreamCreateWithFlags(&hp->down, hipStreamNonBlocking));
+        LSFC_HIP(hipEventCreateWithFlags(&hp->ev_free, hipEventDisableTiming));
+        p->hostpipe = std::move(hp);
+    }
+    HostPipe* hp = p->hostpipe.get();
+    while ((int)hp->ev_up.size() < K) {
+        hipEvent_t a, b;
+        LSFC_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming)); hp->ev_up.push_back(a);
+        LSFC_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming)); hp->ev_down.push_back(b);
+    }
+    const double* nu = use_nu ? p->nu.p : nullptr;
+    hipStream_t st = p->stream;
+    const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
+    const int n = p->dims[0], m = p->dims[1], l = p->dims[2], lz = l / K;
+    const int p1 = p->pitch1, p2 = p->pitch2;
+    const int64_t chunk = (int64_t)n * m * lz, lines = (int64_t)m * lz;
+    // the staging buffers may still be read by work queued earlier on the plan's stream (device-memory calls are asynchronous)
+    LSFC_HIP(hipEventRecord(hp->ev_free, st));
+    LSFC_HIP(hipStreamWaitEvent(hp->up, hp->ev_free, 0));
+    for (int c = 0; c < K; ++c) {
+        const int64_t off = c * chunk;
+        LSFC_HIP(hipMemcpyAsync(p->xs.p + off, x + off, (size_t)chunk * sizeof(cplx), hipMemcpyHostToDevice, hp->up));
+        LSFC_HIP(hipEventRecord(hp->ev_up[c], hp->up));
+        LSFC_HIP(hipStreamWaitEvent(st, hp->ev_up[c], 0));
+        cplx* a1 = p->A1.p + (int64_t)c * lines * p1;
+        pruned_xfwd(Lx, p->tuning, p->xs.p + off, nu ? nu + off : nullptr, a1, p->tw[0].p, lines, Lx, p1, n, st);
+        pruned_yfwd(Ly, p->tuning, a1, p->A2.p + (int64_t)8 * c * lz, p->tw[1].p, Lx, m, lz, p1, p2, st);
+    }
+    pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, p->twl[2].p, Lx, Ly,
+                  (int64_t)p2 * Ly, (int64_t)p2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p, p->zmirror.p, l, st);
+    for (int c = 0; c < K; ++c) {
+        const int64_t off = c * chunk;
+        cplx* a1 = p->A1.p + (int64_t)c * lines * p1;
+        pruned_yinv(Ly, p->tuning, p->A2.p + (int64_t)8 * c * lz, a1, p->tw[1].p, Lx, m, lz, p1, p2, st);
+        pruned_xinv(Lx, p->tuning, a1, p->xs.p + off, p->ys.p + off, alpha, beta, p->tw[0].p, lines, Lx, p1, n, st);
+        LSFC_HIP(hipEventRecord(hp->ev_down[c], st));
+        LSFC_HIP(hipStreamWaitEvent(hp->down, hp->ev_down[c], 0));
+        LSFC_HIP(hipMemcpyAsync(y + off, p->ys.p + off, (size_t)chunk * sizeof(cplx), hipMemcpyDeviceToHost, hp->down));
+    }
+    LSFC_HIP(hipStreamSynchronize(hp->down));
+    LSFC_HIP(hipStreamSynchronize(st));
+}
+
 static void convolve_any(lsfc_plan* p, const double* x, double* y, int64_t nrhs, bool use_nu, double alpha, double beta, int memspace) {
     LSFC_REQUIRE(p && x && y, "NULL argument");
     LSFC_REQUIRE(nrhs >= 1, "nrhs must be >= 1");
@@ -500,20 +577,26 @@ static void convolve_any(lsfc_plan* p, const double* x, double* y, int64_t nrhs,
     LSFC_REQUIRE(memspace == LSFC_MEM_HOST, "unknown memspace %d", memspace);
     const int group = (int)std::min<int64_t>(LSFC_MAX_BATCH, nrhs);
     ensure_staging(p, p->N * group);
+    // large 3D vectors: the chunked pipeline above, one right-hand side after the other
+    const int K = host_pipeline_chunks(p);
+    if (K > 1) {
+        for (int64_t j = 0; j < nrhs; ++j) host_pipelined_convolve(p, (const cplx*)x + j * p->N, (cplx*)y + j * p->N, use_nu, alpha, beta, K);
+        return;
+    }
+    // LSFC_HOST_COPY=sync (developer switch, diagnostics of the round-2 first-apply fault): the round-2 workaround, a
+    // synchronous copy behind a drained stream, instead of the stream-ordered copy
+    static const bool sync_copy = [] { const char* e = getenv("LSFC_HOST_COPY"); return e && e[0] == 's'; }();
     for (int64_t j0 = 0; j0 < nrhs; j0 += group) {
         const int cnt = (int)std::min<int64_t>(group, nrhs - j0);
-        // (synchronous copy of the caller's pageable vector: round 2 saw an intermittent GPU memory fault in the very first
-        // host-vector apply of a process -- first kernel behind an asynchronous copy from pageable memory, garbage fault
-        // address far from every buffer of the plan; the host path is PCIe-bound either way)
-        LSFC_HIP(hipStreamSynchronize(p->stream));
-        LSFC_HIP(hipMemcpy(p->xs.p, (const cplx*)x + j0 * p->N, (size_t)cnt * p->N * sizeof(cplx), hipMemcpyHostToDevice));
-        if (getenv("LSFC_DEBUG_SYNC") && getenv("LSFC_DEBUG_SYNC")[0] == '1')
-            fprintf(stderr, "[lsfc debug] h2d of %lld bytes from %p to %p done; nu %p A1 %p (%zu B) tw0 %p sym %p (%zu B) ys %p\n", (long long)(cnt * p->N * sizeof(cplx)),
-                    (const void*)x, (void*)p->xs.p, (void*)p->nu.p, (void*)p->A1.p, p->A1.bytes(), (void*)p->tw[0].p, (void*)p->sym.p, p->sym.bytes(), (void*)p->ys.p);
+        const size_t bytes = (size_t)cnt * p->N * sizeof(cplx);
+        if (sync_copy) {
+            LSFC_HIP(hipStreamSynchronize(p->stream));
+            LSFC_HIP(hipMemcpy(p->xs.p, (const cplx*)x + j0 * p->N, bytes, hipMemcpyHostToDevice));
+        } else LSFC_HIP(hipMemcpyAsync(p->xs.p, (const cplx*)x + j0 * p->N, bytes, hipMemcpyHostToDevice, p->stream));
         VecBatch vb{};
         for (int j = 0; j < cnt; ++j) { vb.x[j] = p->xs.p + (int64_t)j * p->N; vb.y[j] = p->ys.p + (int64_t)j * p->N; }
         plan_convolve_batch_dev(p, cnt, vb, use_nu, alpha, beta);
-        LSFC_HIP(hipMemcpyAsync((cplx*)y + j0 * p->N, p->ys.p, (size_t)cnt * p->N * sizeof(cplx), hipMemcpyDeviceToHost, p->stream));
+        LSFC_HIP(hipMemcpyAsync((cplx*)y + j0 * p->N, p->ys.p, bytes, hipMemcpyDeviceToHost, p->stream));
         LSFC_HIP(hipStreamSynchronize(p->stream));
     }
 }
@@ -822,6 +905,7 @@ int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value) {
         else if (k == "ytile_z") plan->tuning.ytile_z = value;
         else if (k == "batch_fuse") plan->tuning.batch_fuse = value;
         else if (k == "z_persist") plan->tuning.z_persist = value;
+        else if (k == "xlane") plan->tuning.xlane = value;
         else fail(LSFC_EINVAL, "unknown tuning key '%s'", key);
     });
 }
@@ -918,5 +1002,9 @@ int lsfc_malloc(void** dptr, size_t bytes, int device) {
 int lsfc_free(void* dptr) { return guarded([&] { if (dptr) LSFC_HIP(hipFree(dptr)); }); }
 int lsfc_memcpy_h2d(void* dst, const void* src, size_t bytes) { return guarded([&] { LSFC_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }); }
 int lsfc_memcpy_d2h(void* dst, const void* src, size_t bytes) { return guarded([&] { LSFC_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); }); }
+int lsfc_host_register(void* ptr, size_t bytes) {
+    return guarded([&] { LSFC_REQUIRE(ptr && bytes, "NULL argument"); LSFC_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault)); });
+}
+int lsfc_host_unregister(void* ptr) { return guarded([&] { LSFC_REQUIRE(ptr, "NULL argument"); LSFC_HIP(hipHostUnregister(ptr)); }); }
 
 } // extern "C"

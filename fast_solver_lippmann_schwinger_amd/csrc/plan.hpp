@@ -45,6 +45,14 @@ struct GmresWorkspace {
     ~GmresWorkspace();
 };
 
+// Host-vector apply as a pipeline (plan.hip: host_pipelined_convolve): copy streams and per-chunk events
+struct HostPipe {
+    hipStream_t up = nullptr, down = nullptr;      // non-blocking: ordered against the plan's stream by the events only
+    std::vector<hipEvent_t> ev_up, ev_down;        // chunk c of x has landed / chunk c of y is ready
+    hipEvent_t ev_free = nullptr;                  // everything earlier on the plan's stream has finished with the staging buffers
+    ~HostPipe();
+};
+
 // slab-distributed state (dist.hip)
 struct DistState {
     int rank = 0, nranks = 1;
@@ -124,6 +132,7 @@ struct lsfc_plan {
 
     // staging for host-resident vectors
     lsfc::DevBuf<lsfc::cplx> xs, ys;
+    std::unique_ptr<lsfc::HostPipe> hostpipe;
 
     std::unique_ptr<lsfc::GmresWorkspace> gmres;
     std::vector<std::unique_ptr<lsfc::GmresWorkspace>> gmres_batch;    // one workspace per right-hand side of lsfc_gmres_batch

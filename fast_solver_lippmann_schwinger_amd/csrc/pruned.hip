@@ -39,6 +39,8 @@ void pruned_warmup(int device) {
     static std::set<int> done;
     std::lock_guard<std::mutex> lock(mu);
     if (done.count(device)) return;
+    // LSFC_EAGER_LOAD=0 (developer switch, diagnostics only): leave the code objects to HIP's lazy loading at first launch
+    if (const char* e = getenv("LSFC_EAGER_LOAD")) if (e[0] == '0') return;
     pruned_warmup_f2(); pruned_warmup_f3(); pruned_warmup_f5();
     LSFC_HIP(hipDeviceSynchronize());
     done.insert(device);
@@ -131,6 +133,7 @@ PrunedTuning pruned_default_tuning() {
     if (const char* v = getenv("LSFC_YTILE_Z")) t.ytile_z = atoi(v);
     if (const char* v = getenv("LSFC_BATCH_FUSE")) t.batch_fuse = atoi(v);
     if (const char* v = getenv("LSFC_Z_PERSIST")) t.z_persist = atoi(v);
+    if (const char* v = getenv("LSFC_XLANE")) t.xlane = atoi(v);
     return t;
 }
 

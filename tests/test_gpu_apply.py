@@ -148,12 +148,17 @@ def test_reference_example_size_n48_builder(lsfc):
     assert rel_err(M * b, o.mul(Mo, b)) < TOL
 
 
-@pytest.mark.parametrize("tiled", ["0", "1"])
-@pytest.mark.parametrize("dims", [(256, 256), (512, 384), (200, 1000)])
+@pytest.mark.parametrize("tiled", ["0", "1", None])
+@pytest.mark.parametrize("dims", [(256, 256), (512, 384), (200, 1000), (80, 1024), (24, 800)])
 def test_2d_tiled_and_row_layouts(lsfc, dims, tiled, monkeypatch):
     # the 2D pipeline with the x'-expanded array in rows [m][Lx] or in tiles [Lx/8][m][8] (LSFC_2D_TILED; tiles are the
-    # default from 2048-point lines on): same operator, checked against the oracle on an even (Green's-type) symbol
-    monkeypatch.setenv("LSFC_2D_TILED", tiled)
+    # default from 2048-point lines on): same operator, checked against the oracle on an even (Green's-type) symbol.
+    # (80, 1024), (24, 800): 2048-point y lines next to a short x axis -- Lx / 8 is not a multiple of 8, so the tiled form
+    # (whole groups of 8 tiles) must fall back to natural rows also under the default policy (tiled = None)
+    if tiled is None:
+        monkeypatch.delenv("LSFC_2D_TILED", raising=False)
+    else:
+        monkeypatch.setenv("LSFC_2D_TILED", tiled)
     n, m = dims
     rng = np.random.default_rng(n + m)
     G2 = rng.standard_normal((2 * n, 2 * m)) + 1j * rng.standard_normal((2 * n, 2 * m))
@@ -218,7 +223,7 @@ def test_every_mixed_radix_line_length_on_every_axis_3d(lsfc, L, axis):
 
 
 @pytest.mark.parametrize("short", [0, 6])
-@pytest.mark.parametrize("L", [1024, 1280, 1536, 2048])
+@pytest.mark.parametrize("L", [512, 1024, 1280, 1536, 2048])
 def test_fused_pass_forms_even_symbol_long_z_lines(lsfc, L, short):
     # every form of the fused z pass on the long lines, against the oracle: one tile per workgroup (0), persistent whole
     # tiles (3), ticketed half tiles with per-XCD queues (5; the default at L = 1280 and 1536), ticketed whole tiles (6; the default at 1024).  They need the z-even half symbol,
@@ -236,9 +241,12 @@ def test_fused_pass_forms_even_symbol_long_z_lines(lsfc, L, short):
     want = o.apply_reduced(G2, nu, 2.0, b, (n, m, l))
     got = {}
     for form in (0, 3, 5, 6):
-        M.set_tuning(z_persist=form)
-        got[form] = M * b
-        assert rel_err(got[form], want) < TOL, form
+        # xlane: the exchange between the two radix-8 stages of the 1024- and 1536-point lines through the lanes of the
+        # wavefront (forms 5 and 6) or through LDS
+        for xl in (1, 0):
+            M.set_tuning(z_persist=form, xlane=xl)
+            got[form] = M * b
+            assert rel_err(got[form], want) < TOL, (form, xl)
     # twice in a row through the ticket counters (a fresh set per launch)
     M.set_tuning(z_persist=5)
     assert np.array_equal(M * b, got[5])
@@ -403,6 +411,40 @@ def test_set_nu_and_aliasing(lsfc):
     y = b.copy()
     M.mul_(y, y)                       # y may alias x
     assert rel_err(y, ref) < TOL
+
+
+@pytest.mark.parametrize("K", ["0", "2", "8", "5"])
+def test_host_vector_pipeline(lsfc, K, monkeypatch):
+    # mul!(Y, M, b) with HOST vectors (src/FastConvolution.jl:50-54) as the chunked pipeline (x chunks upload under the x / y
+    # passes, y chunks download under the inverse passes; default for vectors >= 64 MB, forced here on a small grid):
+    # same bits as the one-copy-each-way form and the device-resident apply, also in place (Y aliases b), with page-locked
+    # vectors, and for the bare convolution
+    import torch
+    n, m, l = 24, 20, 40                       # l = 40: 2, 5 and 8 chunks of planes (8 -> the largest divisor below: 8 | 40)
+    rng = np.random.default_rng(5)
+    G2 = rng.standard_normal((2 * n, 2 * m, 2 * l)) + 1j * rng.standard_normal((2 * n, 2 * m, 2 * l))
+    nu = rng.uniform(-0.3, 0.3, n * m * l)
+    b = o.random_vector(n * m * l)
+    M = lsfc.FastM3D(np.fft.fftshift(G2), nu, 2 * n, 2 * m, 2 * l, n, m, l, 2.0)
+    assert M.pipeline == "pruned-hip"
+    want = o.apply_reduced(G2, nu, 2.0, b, (n, m, l))
+    monkeypatch.setenv("LSFC_HOST_PIPELINE", K)
+    y = M * b
+    assert rel_err(y, want) < TOL
+    xd = torch.from_numpy(b).cuda(); yd = torch.empty_like(xd)
+    M.mul_(yd, xd)
+    assert np.array_equal(yd.cpu().numpy(), y)
+    z = b.copy()
+    M.mul_(z, z)                               # in place on the host
+    assert np.array_equal(z, y)
+    bp, yp = b.copy(), np.empty_like(b)
+    lsfc.host_register(bp); lsfc.host_register(yp)
+    try:
+        M.mul_(yp, bp)
+    finally:
+        lsfc.host_unregister(bp); lsfc.host_unregister(yp)
+    assert np.array_equal(yp, y)
+    assert rel_err(lsfc.FFTconvolution(M, b), o.convolve_reduced(G2, b, (n, m, l))) < TOL
 
 
 def test_device_resident_vectors_torch(lsfc):

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fast_solver_lippmann_schwinger_amd as lsfc  # noqa: E402
 
 PEAK = 8.0e12
-BASE = dict(split_x=1, split_s=1, split_z=-1, sym_prefetch=-1, ytile_g=0, ytile_z=0, z_half=-1, tw_lds=1, z_persist=-1)
+BASE = dict(split_x=1, split_s=1, split_z=-1, sym_prefetch=-1, ytile_g=0, ytile_z=0, z_half=-1, tw_lds=1, z_persist=-1, xlane=-1)
 
 VARIANTS = [("auto (persistent pipelined z pass)", {}, {}),
             ("one tile per workgroup (round 1)", {}, dict(z_persist=0)),
@@ -20,7 +20,9 @@ VARIANTS = [("auto (persistent pipelined z pass)", {}, {}),
             ("persistent, whole, symbol after stage 0", {}, dict(z_persist=3)),
             ("persistent, split, symbol after stage 0", {}, dict(z_persist=4)),
             ("persistent half tiles, two workgroups per CU", {}, dict(z_persist=5)),
-            ("persistent whole tiles by tickets", {}, dict(z_persist=6))]
+            ("persistent whole tiles by tickets", {}, dict(z_persist=6)),
+            ("whole tiles by tickets, LDS exchanges only", {}, dict(z_persist=6, xlane=0)),
+            ("half tiles by tickets, LDS exchanges only", {}, dict(z_persist=5, xlane=0))]
 if os.environ.get("PROF_ONLY"):
     keep = [int(i) for i in os.environ["PROF_ONLY"].split(",")]
     VARIANTS = [v for i, v in enumerate(VARIANTS) if i in keep]
