@@ -147,12 +147,13 @@ def cpu_baseline(n_target, nu, xvec):
         Nt, Ns = (2 * n_target) ** 3, (2 * n) ** 3
         scale = (Nt * np.log2(Nt)) / (Ns * np.log2(Ns))
     try:
-        times = timed(n, nu, xvec, 3, 45.0)
+        times = timed(n, nu, xvec, 4, 80.0)        # 1 warm-up + 3 timed at ~14 s each on the GPU box's 256 cores
     except MemoryError:
         return None
     best = min(times[1:]) if len(times) > 1 else times[0]
-    note = (f"oracle reduced-2n apply (scipy.fft, workers={cores}), 3D n={n}, bench contrast and vector, "
-            + (f"1 warm-up + {len(times) - 1} timed, best-of" if len(times) > 1 else "one apply, no warm-up (a second apply did not fit the 45-s sample budget)"))
+    note = (f"oracle reduced-2n apply (scipy.fft, workers={cores}), 3D n={n}, bench contrast and vector, stand-in symbol of the right shape "
+            "(its values do not change the FFT time), "
+            + (f"1 warm-up + {len(times) - 1} timed, best-of" if len(times) > 1 else "one apply, no warm-up (a second apply did not fit the 80-s sample budget)"))
     if n != n_target:
         note += f"; extrapolated to n={n_target} by N log N (x{scale:.2f}): the host cannot hold an n={n_target} apply"
     return {"value": 1.0 / (best * scale), "unit": "applies/s", "cores": cores, "kind": "port", "sample": note,
@@ -327,11 +328,19 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath) and world_eff == 1 and n == 512:
         try:
-            traffic = json.load(open(tpath)).get(dom[0])
-            traffic_src = ("profiles/traffic_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/one_apply.py 512 on this "
-                           "build (per launch; NOT collected in this run -- counters need the profiler)")
-        except Exception:
-            traffic = None
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from csrc_hash import csrc_hash
+            rec = json.load(open(tpath))
+            if rec.get("_csrc_sha256") == csrc_hash(ROOT):
+                traffic = rec.get(dom[0])
+                traffic_src = ("profiles/traffic_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/one_apply.py 512 "
+                               "(tools/pmc_traffic.sh) on the kernel sources of THIS build (sha256 of csrc/ matches; per launch; not collected "
+                               "in this run -- counters need the profiler)")
+            else:
+                traffic_src = ("null: profiles/traffic_latest.json was measured on other kernel sources (sha256 of csrc/ differs) -- re-run "
+                               "tools/pmc_traffic.sh on this build")
+        except Exception as e:
+            traffic, traffic_src = None, f"null: {e}"
     roofline = {"bound": "hbm", "kernel": dom[0], "achieved": dom[2] / (dom[1] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": dom[2] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_over_algorithmic": (traffic / dom[2]) if traffic else None,

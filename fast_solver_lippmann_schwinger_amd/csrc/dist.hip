@@ -12,6 +12,7 @@
 // and the exchange moves 2N complex per transpose, the minimum-volume point of the pipeline.
 #include "plan.hpp"
 #include "pointwise.hpp"
+#include "dist_schedule.hpp"
 #include <rccl/rccl.h>
 #include <cstring>
 #include <string>
@@ -75,29 +76,26 @@ static void phase3(lsfc_plan* p, const cplx* x, cplx* y, double alpha, double be
 // part = -1: whole blocks; 0 / 1: their lower / upper z halves (blocks are [z][m][Wc], z slowest: halves are contiguous)
 static void exchange(lsfc_plan* p, int c, bool back, hipStream_t st, int part = -1) {
     DistState* d = p->dist.get();
-    const int64_t Bfull = block_elems(p), B = part < 0 ? Bfull : Bfull / 2, off = part == 1 ? Bfull / 2 : 0;
-    const int K = d->K, P = d->nranks;
-    auto s1 = [&](int r) { return d->S1.p + ((int64_t)r * K + c) * Bfull + off; };
-    auto r1 = [&](int r) { return d->R1.p + ((int64_t)c * P + r) * Bfull + off; };
-    const cplx* self_src = back ? r1(d->rank) : s1(d->rank);
-    cplx* self_dst = back ? s1(d->rank) : r1(d->rank);
+    const int P = d->nranks;
+    // (the message list -- peers, order, offsets -- is dist_schedule.hpp's, checked on the CPU for P = 2, 4, 8)
+    const std::vector<dsched::Msg> msgs = dsched::exchange_messages(d->rank, P, d->K, c, back, part, block_elems(p));
+    auto ptr = [&](const dsched::Msg& m) { return (m.in_s1 ? d->S1.p : d->R1.p) + m.off; };
     ncclComm_t comm = (ncclComm_t)(back ? d->comm2 : d->comm);
     if (d->force_comm && P == 1) {
         // single-rank exercise of the RCCL path: the self block travels through ncclSend/ncclRecv
         LSFC_NCCL(ncclGroupStart());
-        LSFC_NCCL(ncclSend(self_src, (size_t)B * 2, ncclDouble, 0, comm, st));
-        LSFC_NCCL(ncclRecv(self_dst, (size_t)B * 2, ncclDouble, 0, comm, st));
+        LSFC_NCCL(ncclSend(ptr(msgs[0]), (size_t)msgs[0].count * 2, ncclDouble, 0, comm, st));
+        LSFC_NCCL(ncclRecv(ptr(msgs[1]), (size_t)msgs[1].count * 2, ncclDouble, 0, comm, st));
         LSFC_NCCL(ncclGroupEnd());
         return;
     }
-    LSFC_HIP(hipMemcpyAsync(self_dst, self_src, (size_t)B * sizeof(cplx), hipMemcpyDeviceToDevice, st));
+    LSFC_HIP(hipMemcpyAsync(ptr(msgs[1]), ptr(msgs[0]), (size_t)msgs[0].count * sizeof(cplx), hipMemcpyDeviceToDevice, st));
     if (P == 1) return;
     LSFC_NCCL(ncclGroupStart());
-    for (int s = 1; s < P; ++s) {
-        // pairwise schedule: in step s every GPU talks to a different peer, so all xGMI links carry traffic at once
-        const int to = (d->rank + s) % P, from = (d->rank - s + P) % P;
-        LSFC_NCCL(ncclSend(back ? r1(to) : s1(to), (size_t)B * 2, ncclDouble, to, comm, st));
-        LSFC_NCCL(ncclRecv(back ? s1(from) : r1(from), (size_t)B * 2, ncclDouble, from, comm, st));
+    for (size_t i = 2; i < msgs.size(); ++i) {
+        const dsched::Msg& m = msgs[i];
+        if (m.send) LSFC_NCCL(ncclSend(ptr(m), (size_t)m.count * 2, ncclDouble, m.peer, comm, st));
+        else LSFC_NCCL(ncclRecv(ptr(m), (size_t)m.count * 2, ncclDouble, m.peer, comm, st));
     }
     LSFC_NCCL(ncclGroupEnd());
 }
@@ -211,9 +209,8 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     int K = 4;
     if (const char* v = getenv("LSFC_DIST_CHUNKS")) K = atoi(v);
     if (nranks == 1 && !sim && !getenv("LSFC_DIST_CHUNKS") && !getenv("LSFC_DIST_FORCE_OVERLAP")) K = 1;
-    if (K < 1) K = 1;
-    while (K > 1 && (d->W % K != 0 || (d->W / K) % 8 != 0)) --K;
-    d->K = K; d->Wc = d->W / K;
+    const dsched::Chunks ch = dsched::plan_chunks(p->pads[0], nranks, K);
+    K = ch.K; d->K = ch.K; d->Wc = ch.Wc;
     // LSFC_DIST_FORCE_OVERLAP=1: run the three-stream pipeline even with one rank (tests of the event logic)
     d->force_overlap = getenv("LSFC_DIST_FORCE_OVERLAP") && getenv("LSFC_DIST_FORCE_OVERLAP")[0] == '1';
     // LSFC_DIST_OVERLAP=0: every exchange on the compute stream; LSFC_DIST_SPLIT_EDGES=0: no z-half split of the pipeline ends
@@ -331,18 +328,22 @@ struct Multi {
             }
             return;
         }
+        // every rank's message list is the one its own process would post (dist_schedule.hpp)
+        std::vector<std::vector<dsched::Msg>> msgs((size_t)P);
+        for (int r = 0; r < P; ++r) msgs[(size_t)r] = dsched::exchange_messages(r, P, K, c, back, part, Bfull);
+        auto ptr = [&](int r, const dsched::Msg& m) { return (m.in_s1 ? d(r)->S1.p : d(r)->R1.p) + m.off; };
         for (int r = 0; r < P; ++r) {
             dev(r);
-            LSFC_HIP(hipMemcpyAsync(back ? s1(r, r) : r1(r, r), back ? r1(r, r) : s1(r, r), bytes, hipMemcpyDeviceToDevice, stream(r)));
+            LSFC_HIP(hipMemcpyAsync(ptr(r, msgs[(size_t)r][1]), ptr(r, msgs[(size_t)r][0]), bytes, hipMemcpyDeviceToDevice, stream(r)));
         }
         if (P == 1) return;
         LSFC_NCCL(ncclGroupStart());
         for (int r = 0; r < P; ++r) {
             ncclComm_t comm = (ncclComm_t)(back ? ms->comm2[(size_t)r] : ms->comm[(size_t)r]);
-            for (int s = 1; s < P; ++s) {
-                const int to = (r + s) % P, from = (r - s + P) % P;
-                LSFC_NCCL(ncclSend(back ? r1(r, to) : s1(r, to), (size_t)Bp * 2, ncclDouble, to, comm, stream(r)));
-                LSFC_NCCL(ncclRecv(back ? s1(r, from) : r1(r, from), (size_t)Bp * 2, ncclDouble, from, comm, stream(r)));
+            for (size_t i = 2; i < msgs[(size_t)r].size(); ++i) {
+                const dsched::Msg& m = msgs[(size_t)r][i];
+                if (m.send) LSFC_NCCL(ncclSend(ptr(r, m), (size_t)m.count * 2, ncclDouble, m.peer, comm, stream(r)));
+                else LSFC_NCCL(ncclRecv(ptr(r, m), (size_t)m.count * 2, ncclDouble, m.peer, comm, stream(r)));
             }
         }
         LSFC_NCCL(ncclGroupEnd());

@@ -147,6 +147,10 @@ Base.:\(P::SparsifyingPreconditionerHIP, b::Vector{Complex{Float64}}) = ldiv!(P,
 
 # Device-side GMRES with a host preconditioner: Pl is anything with the two-argument ldiv!(Pl, v)
 # (src/preconditioner.jl:147-170), passed through @cfunction.
+# C layout of lsfc_gmres_opts / lsfc_gmres_result (include/lsfc.h), field: byte offset -- tests/test_abi.py compiles the same
+# table as static_asserts against the header and checks that this comment agrees with it (Julia lays isbits structs out like C)
+# ABI-LAYOUT lsfc_gmres_opts size=64 restart:0 maxiter:8 reltol:16 abstol:24 orth:32 initially_zero:36 precond:40 precond_user:48 precond_on_device:56
+# ABI-LAYOUT lsfc_gmres_result size=32 iters:0 mvps:8 converged:16 final_resnorm:24
 struct GmresOpts
     restart::Cint; maxiter::Int64; reltol::Float64; abstol::Float64; orth::Cint; initially_zero::Cint
     precond::Ptr{Cvoid}; precond_user::Ptr{Cvoid}; precond_on_device::Cint

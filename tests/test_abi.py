@@ -40,6 +40,66 @@ def test_binding_argument_counts_match_the_header():
         assert n == len(args), f"{name}: header has {n} parameters, binding has {len(args)}"
 
 
+def _ctype_class(t):
+    """ctypes type -> one letter: what the C prototype must have in that position"""
+    import ctypes as C
+    if t is None:
+        return "v"
+    if t in (C.c_int,):
+        return "i"
+    if t in (C.c_int64,):
+        return "l"
+    if t in (C.c_double,):
+        return "d"
+    if t in (C.c_uint,):
+        return "u"
+    if t in (C.c_size_t,):
+        return "z"
+    return "p"              # c_void_p, c_char_p, POINTER(...), CFUNCTYPE(...): any object / function pointer
+
+
+def test_binding_argument_types_and_struct_layouts_match_the_header(tmp_path):
+    # A generated C++ translation unit static_asserts, for EVERY prototype of include/lsfc.h, that the return type and each
+    # parameter belong to the class the ctypes binding passes (int / int64_t / double / unsigned / size_t / pointer), and
+    # that offsetof / sizeof of lsfc_gmres_opts and lsfc_gmres_result equal the ctypes Structures' -- a c_int <-> int64_t slip
+    # or a reordered struct field fails to compile.  The same layout table is quoted in julia/FastConvHIP.jl.
+    import ctypes as C
+    import fast_solver_lippmann_schwinger_amd._lib as L
+    lines = ['#include <cstddef>', '#include <cstdint>', '#include <type_traits>', '#include "lsfc.h"',
+             'template <class T> constexpr char cls() {',
+             '  if constexpr (std::is_void<T>::value) return \'v\'; else if constexpr (std::is_pointer<T>::value) return \'p\';',
+             '  else if constexpr (std::is_same<T, int>::value) return \'i\'; else if constexpr (std::is_same<T, int64_t>::value) return \'l\';',
+             '  else if constexpr (std::is_same<T, double>::value) return \'d\'; else if constexpr (std::is_same<T, unsigned>::value) return \'u\';',
+             '  else if constexpr (std::is_same<T, size_t>::value) return \'z\'; else return \'?\'; }',
+             'template <class R, class... A> constexpr bool sig(R (*)(A...), const char* want) {',
+             '  const char got[] = { cls<R>(), cls<A>()..., 0 };',
+             '  for (int i = 0;; ++i) { if (got[i] != want[i]) return false; if (!got[i]) return true; } }']
+    for name, (res, args) in sorted(L.SIGNATURES.items()):
+        want = _ctype_class(res) + "".join(_ctype_class(a) for a in args)
+        lines.append(f'static_assert(sig(&{name}, "{want}"), "{name}: binding passes {want}");')
+    table = {}
+    for cname, st in (("lsfc_gmres_opts", L.GmresOpts), ("lsfc_gmres_result", L.GmresResult)):
+        lines.append(f'static_assert(sizeof({cname}) == {C.sizeof(st)}, "sizeof {cname}");')
+        row = [f"size={C.sizeof(st)}"]
+        for fname, _ in st._fields_:
+            off = getattr(st, fname).offset
+            lines.append(f'static_assert(offsetof({cname}, {fname}) == {off}, "{cname}.{fname}");')
+            row.append(f"{fname}:{off}")
+        table[cname] = " ".join(row)
+    src = tmp_path / "abi_check.cpp"
+    src.write_text("\n".join(lines) + "\nint main() { return 0; }\n")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    # the Julia binding's structs (same field order and types by eye) quote the same offsets
+    jl = open(os.path.join(ROOT, "julia", "FastConvHIP.jl")).read()
+    for cname, row in table.items():
+        assert f"# ABI-LAYOUT {cname} {row}" in jl, f"julia/FastConvHIP.jl: layout comment of {cname} should read: {row}"
+    # ... and its struct definitions list exactly those fields in that order
+    for jname, st in (("GmresOpts", L.GmresOpts), ("GmresResult", L.GmresResult)):
+        body = re.search(r"struct %s\n(.*?)\nend" % jname, jl, flags=re.S).group(1)
+        assert re.findall(r"(\w+)::", body) == [f for f, _ in st._fields_], jname
+
+
 def test_padded_length_rule():
     # host arithmetic only: smallest of 2^k, 3*2^k, 5*2^k in [32, 2048] that is >= 2n
     import fast_solver_lippmann_schwinger_amd._lib as L

@@ -38,6 +38,8 @@ for k in fetch:
     latest[s] = rd + wr
 json.dump({"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 tools/one_apply.py 512 3; gfx950 corrections per MI355X_MICROARCH.md",
            "kernels": out}, open("$OUT/pmc_traffic.json", "w"), indent=1)
+import sys; sys.path.insert(0, "$R/tools"); from csrc_hash import csrc_hash
+latest["_csrc_sha256"] = csrc_hash("$R")           # bench.py reports the traffic only for the build it was measured on
 json.dump(latest, open("$OUT/traffic_latest.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 EOF
