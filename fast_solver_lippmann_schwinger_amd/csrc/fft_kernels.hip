@@ -374,7 +374,10 @@ template <class C, int LINES, bool SPLIT, bool TWL, bool HALF> constexpr size_t 
 // TICKETS without HALF: whole tiles handed out the same way, in pairs (row, mirror row) per XCD queue.
 // XL: the exchange between the two radix-8 stages of the line runs through the lanes of the wavefront (fft_core.hpp:
 // xlane_transpose8) instead of LDS -- one LDS exchange and two workgroup barriers less per direction.
-template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL, bool LATE_SYM = false, bool HALF = false, bool TICKETS = HALF, bool XL = false>
+// XL & 2: in addition the mirror values of the z-even symbol (slots e >= E/2: the entry of frequency L - kz) are loaded by the
+// thread that needs them, a second read of lines this workgroup fetches anyway (L2 hits), instead of being staged through
+// LDS by the threads that hold them: 8 ds_write_b128 + 8 ds_read_b128 per thread and one of the two barriers around them go.
+template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL, bool LATE_SYM = false, bool HALF = false, bool TICKETS = HALF, int XL = 0>
 __global__ __launch_bounds__(C::T * LINES, (HALF && 2 * persist_lds_bytes<C, LINES, SPLIT, TWL, HALF>() <= (size_t)160 * 1024) ? 2 : 1)
 void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx* __restrict__ tw,
                       int nouter, int64_t dGrp, int64_t dOuter, int64_t dLine, int64_t sGrp, int64_t sOuter, int64_t sLine,
@@ -402,6 +405,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
     unsigned cur = blockIdx.x, nwork = ntiles;
     unsigned* slot = nullptr;                           // HALF: where thread 0 publishes the work item it drew
     unsigned queue = 0, queues_left = 8;                // HALF, thread 0: the queue it draws from, queues not yet seen empty
+    [[maybe_unused]] unsigned parity = 1u;              // XL = 2: which of the two ticket slots the next publication uses (slot[0]: the first draw)
     auto draw = [&]() -> unsigned {                     // (thread 0 only)
         while (queues_left > 0) {
             const unsigned c = atomicAdd(tickets + queue, 1u);
@@ -443,12 +447,20 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
     // (unsigned: scalar base + zero-extended 32-bit lane offset is an addressing mode of the global instructions)
     const unsigned doff = (unsigned)(li + (int)dLine * t), dstep = (unsigned)((int)dLine * T);      // element j = t + T e of this thread's line
     const unsigned soff = (unsigned)(li + (int)sLine * t), sstep = (unsigned)((int)sLine * T);
+    // (element e of the thread: the uniform part dstep * e goes into the scalar base, the lane's part stays ONE 32-bit offset --
+    // written as (base + dstep * e)[doff]: as base[doff + dstep * e] the 32-bit sum may wrap, so the compiler must add per lane)
+    constexpr bool MIRG = (XL & 2) != 0;
+    [[maybe_unused]] unsigned moff[MIRG ? H : 1];      // MIRG: element index of the mirror entry of slot e + H in this thread's symbol line
+    if constexpr (MIRG) {
+#pragma unroll
+        for (int e = 0; e < H; ++e) moff[e] = (unsigned)(li + (int)sLine * zm[t + T * e]);
+    }
     cplx nd[H];                                        // data of the tile about to be transformed
     {
         cplx* d; const cplx* s;
         locate(cur, d, s);
 #pragma unroll
-        for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? d[doff + dstep * e] : make_double2(0.0, 0.0);
+        for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? (d + (size_t)dstep * e)[doff] : make_double2(0.0, 0.0);
     }
     for (;;) {
         // HALF: draw the next ticket now; it is published and read around the barriers of the symbol multiply below
@@ -458,19 +470,25 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
 #pragma unroll
         for (int e = 0; e < H; ++e) { v[e] = nd[e]; v[e + H] = make_double2(0.0, 0.0); }
         cplx sv[H];
+        [[maybe_unused]] cplx smr[MIRG ? H : 1];
         cplx smid = make_double2(0.0, 0.0);
         auto load_symbol = [&] {
             cplx* d; const cplx* s;
             locate(cur, d, s);
             const unsigned so = launder_v(soff);
 #pragma unroll
-            for (int e = 0; e < H; ++e) sv[e] = s[so + sstep * e];
-            if (t == 0) smid = s[so - (unsigned)((int)sLine * t) + (unsigned)((int)sLine * (C::L / 2))];
+            for (int e = 0; e < H; ++e) sv[e] = (s + (size_t)sstep * e)[so];
+            if constexpr (MIRG) {
+#pragma unroll
+                for (int e = 0; e < H; ++e) smr[e] = s[moff[e]];
+            } else {
+                if (t == 0) smid = s[so - (unsigned)((int)sLine * t) + (unsigned)((int)sLine * (C::L / 2))];
+            }
         };
         if constexpr (!SPLIT && WS) {
             // exchange stores issued from inside the stages (fft_forward_ws); the symbol is loaded after the first stage
             if constexpr (!LATE_SYM) load_symbol();
-            fft_forward_ws<C, LL, true, TWL, DEFER, XL>(v, t, tw, smem, 0, li, [&] { if constexpr (LATE_SYM) load_symbol(); });
+            fft_forward_ws<C, LL, true, TWL, DEFER, (XL > 0)>(v, t, tw, smem, 0, li, [&] { if constexpr (LATE_SYM) load_symbol(); });
         } else if constexpr (LATE_SYM) {
             // the first forward stage (the widest butterfly plus its twiddles) runs before the symbol values occupy registers
             stage<C, 0, +1, 1, TWL>(v, t, tw);
@@ -484,6 +502,19 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
             fft_forward<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         }
         cplx* stage = reinterpret_cast<cplx*>(smem);
+        unsigned next = cur + gridDim.x;
+        if constexpr (MIRG) {
+            // no staging: every thread holds its own mirror values.  The ticket travels through a slot of its own per tile parity,
+            // so ONE barrier publishes it (the slot of the other parity is rewritten only two barriers later)
+#pragma unroll
+            for (int e = 0; e < H; ++e) { v[e] = cmul(v[e], sv[e]); v[e + H] = cmul(v[e + H], smr[e]); }
+            if constexpr (TICKETS) {
+                if (threadIdx.x == 0) slot[parity] = drawn;
+                LSFC_BARRIER();
+                next = __builtin_amdgcn_readfirstlane(slot[parity]);
+                parity ^= 1u;
+            }
+        } else {
         // other waves may still read the exchange buffer (wave-local last exchange, or the deferred barrier of fft_forward_ws)
         if constexpr (forward_ends_local<C, LL>() || (!SPLIT && WS && DEFER)) LSFC_BARRIER();
 #pragma unroll
@@ -500,25 +531,25 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
             }
         }
         // next tile: its loads travel while this tile is transformed back
-        unsigned next = cur + gridDim.x;
         if constexpr (TICKETS) next = __builtin_amdgcn_readfirstlane(*slot);
         LSFC_BARRIER();
+        }
         const bool more = TICKETS ? next != DONE : next < nwork;
         if (more) {
             cplx* dn; const cplx* sn;
             locate(next, dn, sn);
             const unsigned dof = launder_v(doff);
 #pragma unroll
-            for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? dn[dof + dstep * e] : make_double2(0.0, 0.0);
+            for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? (dn + (size_t)dstep * e)[dof] : make_double2(0.0, 0.0);
         }
-        if constexpr (!SPLIT && WS) fft_inverse_ws<C, LL, true, TWL, DEFER, XL>(v, t, tw, smem, 0, li);
+        if constexpr (!SPLIT && WS) fft_inverse_ws<C, LL, true, TWL, DEFER, (XL > 0)>(v, t, tw, smem, 0, li);
         else fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         {
             cplx* d; const cplx* s;
             locate(cur, d, s);
             const unsigned dof = launder_v(doff);
 #pragma unroll
-            for (int e = 0; e < H; ++e) if (EXACT || t + T * e < nin) d[dof + dstep * e] = v[e];
+            for (int e = 0; e < H; ++e) if (EXACT || t + T * e < nin) (d + (size_t)dstep * e)[dof] = v[e];
         }
         if (!more) break;
         cur = next;
@@ -648,7 +679,7 @@ static int cu_count() {
 static unsigned* ticket_set(hipStream_t st);
 template <class C, bool SPLIT, bool LATE_SYM = false, bool TICKETS = false> static void zfused_persist_t(cplx* data, const cplx* sym, const cplx* tw, const cplx* twl, int Lx, int nouter,
                                                             int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                                                            const int2* ytab, const int* zm, int nin, hipStream_t st, bool xl = false) {
+                                                            const int2* ytab, const int* zm, int nin, hipStream_t st, int xl = 0) {
     constexpr int LINES = XB;
     using LL = LdsLayout<LINES, 3, SPLIT>;
     size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
@@ -661,12 +692,16 @@ template <class C, bool SPLIT, bool LATE_SYM = false, bool TICKETS = false> stat
     }
     // lane exchange between the two radix-8 stages (ticketed whole tiles, symbol after the first stage: the 512^3 form)
     if constexpr (xlane_ok<C, LL>() && LATE_SYM && TICKETS) {
-        if (xl) {
-            if (twl) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, true> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, true>;
-            else     k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false, LATE_SYM, false, TICKETS, true> : k_zfused_persist<C, LINES, SPLIT, false, false, LATE_SYM, false, TICKETS, true>;
+        if (xl == 1) {
+            if (twl) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, 1> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, 1>;
+            else     k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false, LATE_SYM, false, TICKETS, 1> : k_zfused_persist<C, LINES, SPLIT, false, false, LATE_SYM, false, TICKETS, 1>;
+        } else if (xl >= 2 && twl) {
+            // 3: + mirror symbol values from L2 (XL & 2; measured slower, profiles/r03_experiment_fused_pass_variants.log)
+            if (xl == 3) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, 3> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, 3>;
+            else k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, 1> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, 1>;
         }
     }
-    if (TICKETS) lds += 16;                             // the ticket slot
+    if (TICKETS) lds += 16;                             // the ticket slots
     allow_lds(k, lds);
     const int cus = cu_count();
     const unsigned ntiles = (unsigned)((Lx / XB) * nouter);
@@ -700,14 +735,14 @@ static unsigned* ticket_set(hipStream_t st) {
 // the same on half tiles: 4-line workgroups with the twiddle table, as many per CU as the LDS holds (two at L = 1024)
 template <class C> static void zfused_persist_half_t(cplx* data, const cplx* sym, const cplx* twl, int Lx, int nouter,
                                                      int64_t dTile, int64_t dOuter, int64_t dLine, int64_t sTile, int64_t sOuter, int64_t sLine,
-                                                     const int2* ytab, const int* zm, int nin, hipStream_t st, bool xl = false) {
+                                                     const int2* ytab, const int* zm, int nin, hipStream_t st, int xl = 0) {
     if constexpr (C::L >= 1024) {
         constexpr int LINES = XB / 2;
         constexpr size_t lds = persist_lds_bytes<C, LINES, false, true, true>() + 16;   // + the ticket slot
         static_assert(lds <= (size_t)160 * 1024, "half-tile persistent pass: exchange buffer exceeds the LDS");
         auto k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, false, true, true, true, true> : k_zfused_persist<C, LINES, false, false, true, true, true>;
         if constexpr (xlane_ok<C, LdsLayout<LINES, -1, false>>()) {
-            if (xl) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, false, true, true, true, true, true, true> : k_zfused_persist<C, LINES, false, false, true, true, true, true, true>;
+            if (xl) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, false, true, true, true, true, true, 1> : k_zfused_persist<C, LINES, false, false, true, true, true, true, 1>;
         }
         LSFC_REQUIRE(twl != nullptr, "half-tile persistent pass: twiddle table missing");
         allow_lds(k, lds);
@@ -857,13 +892,13 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
             const bool split = zp == 2 || zp == 4 || full_lds > (size_t)160 * 1024;
             // 5: half tiles (4-line workgroups, swizzled unpadded exchange buffer + twiddle table), two workgroups per CU at L = 1024
             if (half5) {
-                LSFC_DISPATCH_L(L, (zfused_persist_half_t<C>(data, sym, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, tn.xlane != 0)));
+                LSFC_DISPATCH_L(L, (zfused_persist_half_t<C>(data, sym, twl, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, tn.xlane != 0 ? 1 : 0)));
                 LSFC_HIP(hipGetLastError());
                 return;
             }
             // 6: whole tiles (as 3) handed out by tickets in row pairs per XCD
             if (zp == 6 && !split && ((int64_t)(Lx / XB) * nouter) % 16 == 0 && nouter % 2 == 0) {
-                LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, tn.xlane != 0)));
+                LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, tn.xlane < 0 ? 1 : tn.xlane)));
                 LSFC_HIP(hipGetLastError());
                 return;
             }

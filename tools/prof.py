@@ -22,6 +22,9 @@ VARIANTS = [("auto (persistent pipelined z pass)", {}, {}),
             ("persistent half tiles, two workgroups per CU", {}, dict(z_persist=5)),
             ("persistent whole tiles by tickets", {}, dict(z_persist=6)),
             ("whole tiles by tickets, LDS exchanges only", {}, dict(z_persist=6, xlane=0)),
+            ("whole tiles, lane exchange", {}, dict(z_persist=6, xlane=1)),
+            ("whole tiles, lane exchange + mirror symbol from L2", {}, dict(z_persist=6, xlane=3)),
+
             ("half tiles by tickets, LDS exchanges only", {}, dict(z_persist=5, xlane=0))]
 if os.environ.get("PROF_ONLY"):
     keep = [int(i) for i in os.environ["PROF_ONLY"].split(",")]
