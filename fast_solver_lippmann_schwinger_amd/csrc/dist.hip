@@ -452,8 +452,16 @@ void multi_allreduce_sum(lsfc_plan* root, cplx* const* dev, int count) {
         LSFC_NCCL(ncclGroupEnd());
         return;
     }
-    // copy transport: O(restart) scalars through pinned host memory, summed in rank order (reproducible)
-    LSFC_REQUIRE(count <= 256, "internal: reduction of %d scalars", count);
+    // copy transport: O(restart) scalars through pinned host memory, summed in rank order (reproducible); the pinned scratch
+    // holds 256 scalars per rank, longer reductions (classical Gram-Schmidt with restart > 256) go in pieces
+    if (count > 256) {
+        for (int c0 = 0; c0 < count; c0 += 256) {
+            std::vector<cplx*> piece((size_t)M.P);
+            for (int r = 0; r < M.P; ++r) piece[(size_t)r] = dev[r] + c0;
+            multi_allreduce_sum(root, piece.data(), std::min(256, count - c0));
+        }
+        return;
+    }
     cplx* pin = M.ms->red_pin;
     for (int r = 0; r < M.P; ++r) { M.dev(r); LSFC_HIP(hipMemcpyAsync(pin + (size_t)(r + 1) * 256, dev[r], (size_t)count * sizeof(cplx), hipMemcpyDeviceToHost, M.st(r))); }
     for (int r = 0; r < M.P; ++r) { M.dev(r); LSFC_HIP(hipStreamSynchronize(M.st(r))); }
@@ -463,6 +471,8 @@ void multi_allreduce_sum(lsfc_plan* root, cplx* const* dev, int count) {
         pin[i] = acc;
     }
     for (int r = 0; r < M.P; ++r) { M.dev(r); LSFC_HIP(hipMemcpyAsync(dev[r], pin, (size_t)count * sizeof(cplx), hipMemcpyHostToDevice, M.st(r))); }
+    // (the next reduction rewrites the pinned scratch: it starts with copies INTO it that are stream-ordered behind these, and the
+    // host only touches it after synchronising every rank's stream above)
 }
 
 // per-stage timing of one apply on the ranks' staging vectors: every stage runs on all ranks, un-overlapped, with a

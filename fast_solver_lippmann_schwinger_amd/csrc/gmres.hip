@@ -214,6 +214,10 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
     // one device, no all-reduce between a reduction and its consumer: the fused kernels (pointwise.hip) sum block partials
     // inside the consuming kernel -- same summation order, bit-identical scalars, roughly half the launches
     const bool fused = !T.reduce && T.mem.size() == 1;
+    // modified Gram-Schmidt in blocks (pointwise.hip: k_mgs_block) where the sweep is bound by HBM traffic: vectors of >= 2^22
+    // entries (LSFC_MGS_BLOCK=0 / 1 forces the strict one-vector-at-a-time sweep / the blocked one)
+    const char* mb_env = getenv("LSFC_MGS_BLOCK");
+    const bool mgs_blocked = mb_env ? atoi(mb_env) != 0 : Ntot >= ((int64_t)1 << 22);
     auto slot = [&](int s2) { return T.mem[0].w->partial.p + (size_t)s2 * (size_t)blas_partial_slot(); };
     auto cgs_sweep = [&](int k, bool scale_now, int hslot = 0, bool wait = true) {
         if (fused && k <= 64) {
@@ -274,7 +278,22 @@ void solve(Team& T, const lsfc_gmres_opts* opts_in, double* resnorm, int64_t cap
         const int hs = kk & 1;
         T.apply([kk](const Member& m) { return (const cplx*)Team::V(m, kk - 1); }, [kk](const Member& m) { return Team::V(m, kk); });
         precondition(kk);
-        if (o.orth == LSFC_ORTH_MGS && fused) {
+        if (o.orth == LSFC_ORTH_MGS && fused && mgs_blocked) {
+            // blocks of MB basis vectors: one pass takes the inner products with a whole block (and of its vectors with each
+            // other), the next one recovers the MGS coefficients, updates w with the block and takes the next block's products
+            Member& m = T.mem[0];
+            Team::dev(m);
+            const int MB = blas_mgs_block_size(), S = blas_mgs_slots();
+            const int nblk = (kk + MB - 1) / MB;
+            blas_mgs_block(Team::V(m, kk), nullptr, 0, nullptr, nullptr, Team::V(m, 0), std::min(MB, kk), slot(0), m.p->N, m.p->N, m.p->stream);
+            for (int b = 0; b < nblk; ++b) {
+                const int i0 = b * MB, mp = std::min(MB, kk - i0), mn = std::max(0, std::min(MB, kk - i0 - MB));
+                blas_mgs_block(Team::V(m, kk), Team::V(m, i0), mp, slot((b & 1) * S), m.w->hdev.p + i0, mn ? Team::V(m, i0 + MB) : nullptr, mn,
+                               slot(((b + 1) & 1) * S), m.p->N, m.p->N, m.p->stream);
+            }
+            blas_scale_inv_fused(Team::V(m, kk), slot((nblk & 1) * S), m.w->hdev.p + kk, m.p->N, m.p->stream);
+            T.fetch_post(kk + 1, hs);
+        } else if (o.orth == LSFC_ORTH_MGS && fused) {
             Member& m = T.mem[0];
             Team::dev(m);
             blas_dot_partial(Team::V(m, 0), Team::V(m, kk), slot(0), m.p->N, m.p->stream);
@@ -402,7 +421,20 @@ void gmres_run_batch(lsfc_plan* p, cplx* x, const cplx* b, int nrhs, const lsfc_
                      lsfc_gmres_result* res) {
     const Resolved r = resolve(opts_in, p->N);
     const bool need_vpin = r.o.precond != nullptr && !r.o.precond_on_device;
-    // one workspace (Krylov basis, scalars, pinned buffers) per right-hand side
+    // one workspace (Krylov basis, scalars, pinned buffers) per right-hand side: nrhs * (restart + 2) vectors of N complex.
+    // Checked against the free device memory up front (a failed hipMalloc half way through leaves a half-built batch), and
+    // released again when the call returns -- the single-solve workspace of the plan is the one that is kept across calls.
+    {
+        size_t free_b = 0, total_b = 0;
+        LSFC_HIP(hipMemGetInfo(&free_b, &total_b));
+        size_t have = 0;
+        for (auto& w : p->gmres_batch) if (w && w->restart >= r.restart) have += w->V.bytes() + w->ax.bytes();
+        const double need = (double)nrhs * ((double)r.restart + 2.0) * (double)p->N * sizeof(cplx);
+        if (need > (double)free_b + (double)have)
+            fail(LSFC_ENOMEM, "lsfc_gmres_batch: %d right-hand sides x (restart %d + 2) vectors of %lld complex need %.1f GB of device memory, %.1f GB are free "
+                 "-- solve fewer right-hand sides per call or lower the restart length", nrhs, r.restart, (long long)p->N, need / 1e9, ((double)free_b + (double)have) / 1e9);
+    }
+    struct Release { lsfc_plan* p; ~Release() { p->gmres_batch.clear(); } } release_on_return{p};
     if ((int)p->gmres_batch.size() < nrhs) p->gmres_batch.resize((size_t)nrhs);
     for (int j = 0; j < nrhs; ++j) {
         std::unique_ptr<GmresWorkspace> keep = std::move(p->gmres);

@@ -452,6 +452,109 @@ __global__ __launch_bounds__(RED_THREADS) void k_scale_inv_fused(cplx* __restric
     }
 }
 
+// Modified Gram-Schmidt in blocks of MB basis vectors (large vectors: the sweep is pure HBM traffic).  Strict MGS takes the
+// inner product with v_{i+1} only after w has been updated with v_i: four passes over N-vectors per basis vector (read w, v_i,
+// v_{i+1}, write w).  But  <v_j, w - sum_{l<j} h_l v_l> = <v_j, w> - sum_{l<j} h_l <v_j, v_l>,  so ONE pass over w and the MB
+// vectors of a block yields the MB inner products with the not-yet-updated w plus the MB (MB - 1) / 2 inner products of the
+// block's vectors with each other (they cost no memory traffic: the vectors are in registers anyway), from which every
+// workgroup of the next kernel recovers the MGS coefficients h_0 .. h_{MB-1} by the recurrence above -- the same numbers
+// modified Gram-Schmidt produces, up to the order of rounding.  That kernel updates w with the whole block and, in the same
+// pass, takes the inner products with the NEXT block (or |w|^2 after the last).  Passes per basis vector: 2 + 2 / MB (MB = 4:
+// 2.5 instead of 4).  Partials: slot base + j (j < MB) = <v_j, w>, base + MB + pair(j, l) = <v_j, v_l> for l < j.
+template <int MB> __device__ __forceinline__ constexpr int mgs_pair(int j, int l) { return j * (j - 1) / 2 + l; }     // l < j
+template <int MB>
+__global__ __launch_bounds__(RED_THREADS) void k_mgs_block(cplx* __restrict__ w, const cplx* __restrict__ Vp, int mp, const cplx* __restrict__ ppartial, int nb,
+                                                            cplx* __restrict__ hout, const cplx* __restrict__ Vn, int mn, cplx* __restrict__ npartial,
+                                                            int64_t ldv, int64_t n) {
+    constexpr int NP = MB * (MB - 1) / 2;
+    __shared__ cplx sh[RED_THREADS / 64];
+    __shared__ cplx fin[MB + NP];
+    __shared__ cplx hs[MB];
+    if (mp > 0) {
+        const int ns = mp + mp * (mp - 1) / 2;             // (slots of a short block are numbered as those of a full one: pair(j, l) does not depend on mp)
+        for (int q = threadIdx.x >> 6; q < MB + NP; q += RED_THREADS / 64) {
+            const bool used = q < mp || (q >= MB && q - MB < mp * (mp - 1) / 2);
+            if (used) { const cplx v = finish_in_wave(ppartial + (int64_t)q * RED_BLOCKS, nb); if ((threadIdx.x & 63) == 0) fin[q] = v; }
+        }
+        (void)ns;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            cplx h[MB];
+            for (int j = 0; j < mp; ++j) {
+                cplx a = fin[j];
+                for (int l = 0; l < j; ++l) {               // a -= h_l * <v_j, v_l>
+                    const cplx g = fin[MB + mgs_pair<MB>(j, l)];
+                    a.x -= fma(h[l].x, g.x, -h[l].y * g.y);
+                    a.y -= fma(h[l].x, g.y, h[l].y * g.x);
+                }
+                h[j] = a; hs[j] = a;
+                if (blockIdx.x == 0) hout[j] = a;
+            }
+        }
+        __syncthreads();
+    }
+    cplx c[MB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) c[j] = j < mp ? hs[j] : make_double2(0.0, 0.0);
+    cplx ad[MB], ag[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) ad[j] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) ag[j] = make_double2(0.0, 0.0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        cplx x = w[i];
+        if (mp > 0) {
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                if (j < mp) {
+                    const cplx q = Vp[(int64_t)j * ldv + i];
+                    x.x -= fma(c[j].x, q.x, -c[j].y * q.y);
+                    x.y -= fma(c[j].x, q.y, c[j].y * q.x);
+                }
+            }
+            w[i] = x;
+        }
+        if (mn > 0) {
+            cplx u[MB];
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                if (j < mn) {
+                    u[j] = Vn[(int64_t)j * ldv + i];
+                    ad[j].x = fma(u[j].x, x.x, fma(u[j].y, x.y, ad[j].x));
+                    ad[j].y = fma(u[j].x, x.y, fma(-u[j].y, x.x, ad[j].y));
+#pragma unroll
+                    for (int l = 0; l < j; ++l) {           // <v_j, v_l> = sum conj(v_j) v_l
+                        cplx& g = ag[mgs_pair<MB>(j, l)];
+                        g.x = fma(u[j].x, u[l].x, fma(u[j].y, u[l].y, g.x));
+                        g.y = fma(u[j].x, u[l].y, fma(-u[j].y, u[l].x, g.y));
+                    }
+                }
+            }
+        } else {
+            ad[0].x = fma(x.x, x.x, fma(x.y, x.y, ad[0].x));            // after the last block: |w|^2
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MB + NP; ++q) {
+        const bool used = mn > 0 ? (q < mn || (q >= MB && q - MB < mn * (mn - 1) / 2)) : q == 0;
+        if (used) {
+            const cplx r = block_sum(q < MB ? ad[q] : ag[q - MB], sh);
+            if (threadIdx.x == 0) npartial[(int64_t)q * RED_BLOCKS + blockIdx.x] = r;
+            __syncthreads();
+        }
+    }
+}
+// one kernel of the blocked sweep: w -= Vp h (h from the partials `ppartial` of the previous kernel, published in hout; mp = 0:
+// nothing to subtract, w is only read), then the partials of the inner products with the mn <= MB vectors Vn (mn = 0: of |w|^2,
+// slot 0) into `npartial`; both partial areas hold blas_mgs_slots() slots
+int blas_mgs_block_size() { return 4; }
+int blas_mgs_slots() { return 4 + 6; }
+void blas_mgs_block(cplx* w, const cplx* Vp, int mp, const cplx* ppartial, cplx* hout, const cplx* Vn, int mn, cplx* npartial, int64_t ldv, int64_t n, hipStream_t st) {
+    LSFC_REQUIRE(mp >= 0 && mp <= 4 && mn >= 0 && mn <= 4, "mgs block: at most 4 vectors per block");
+    hipLaunchKernelGGL(k_mgs_block<4>, dim3(red_blocks(n)), dim3(RED_THREADS), 0, st, w, Vp, mp, ppartial, red_blocks(n), hout, Vn, mn, npartial, ldv, n);
+    LSFC_HIP(hipGetLastError());
+}
+
 int blas_red_blocks(int64_t n) { return red_blocks(n); }
 int blas_partial_slot() { return RED_BLOCKS; }
 // out.x = sqrt(sum partial[0..nb).x): the norm from its block partials (the DGKS test needs it on the host before scaling)

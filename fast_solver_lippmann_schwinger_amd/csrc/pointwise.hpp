@@ -43,6 +43,11 @@ void blas_axpy_dot_fused(cplx* w, const cplx* v, const cplx* hpartial, cplx* hou
 void blas_multidot_partial(const cplx* V, int64_t ldv, int k, const cplx* w, cplx* partial, int64_t n, hipStream_t);
 void blas_cgs_update_fused(cplx* w, const cplx* V, int64_t ldv, int k, const cplx* hpartial, cplx* hout, cplx* npartial, int64_t n, hipStream_t);
 void blas_scale_inv_fused(cplx* a, const cplx* npartial, cplx* nout, int64_t n, hipStream_t);
+// modified Gram-Schmidt in blocks of blas_mgs_block_size() basis vectors (pointwise.hip: k_mgs_block): 2 + 2 / MB passes over
+// N-vectors per basis vector instead of 4
+int  blas_mgs_block_size();
+int  blas_mgs_slots();                          // partial slots one kernel of the blocked sweep writes / reads
+void blas_mgs_block(cplx* w, const cplx* Vp, int mp, const cplx* ppartial, cplx* hout, const cplx* Vn, int mn, cplx* npartial, int64_t ldv, int64_t n, hipStream_t);
 void blas_scale_inv_dev(cplx* a, const cplx* s, int64_t n, hipStream_t);                                   // a /= s[0].x
 
 } // namespace lsfc

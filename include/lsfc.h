@@ -190,7 +190,8 @@ int lsfc_gmres(lsfc_plan* plan, double* x, const double* b, const lsfc_gmres_opt
  * test -- its iterates are those of lsfc_gmres on that right-hand side alone -- but every Arnoldi step applies the
  * operator to all unconverged right-hand sides in one batched pass (see lsfc_apply_batch).  Host preconditioner
  * callbacks are invoked one at a time.  Returns LSFC_OK even if some right-hand side hit maxiter: check
- * results[j].converged. */
+ * results[j].converged.  Device memory: nrhs * (restart + 2) vectors of N complex for the duration of the call (checked
+ * against the free memory up front: LSFC_ENOMEM with the figures; released on return). */
 int lsfc_gmres_batch(lsfc_plan* plan, double* x, const double* b, int64_t nrhs, const lsfc_gmres_opts* opts,
                      double* resnorm, int64_t resnorm_cap, lsfc_gmres_result* results, int memspace);
 

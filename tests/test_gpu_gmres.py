@@ -38,6 +38,33 @@ def test_gmres_history_matches_golden(lsfc):
     assert rel_err(u, g["u"]) < 1e-8
 
 
+@pytest.mark.parametrize("restart", [3, 4, 9, 13])
+def test_gmres_blocked_mgs_matches_oracle_and_strict_sweep(lsfc, restart, monkeypatch):
+    # modified Gram-Schmidt in blocks of four basis vectors (the default for vectors of >= 2^22 entries, forced here on a small
+    # grid): residual history against oracle.gmres to the usual 1e-6, against the strict one-vector-at-a-time sweep to rounding;
+    # restart lengths that end blocks at 3 / 4 / 4+4+1 / 4+4+4+1 vectors
+    c, Mo, M, rhs = _setup(lsfc, "gv16k10")
+    n = c["n"]
+    G2 = o.reduce_symbol(Mo.GFFT, (n, n, n))
+    A = lambda v: o.apply_reduced(G2, Mo.nu, Mo.omega, v, (n, n, n))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LSFC_MGS_BLOCK", mode)
+        u = np.zeros(M.N, complex)
+        out[mode] = lsfc.gmres_(u, M, rhs, restart=restart, maxiter=40, reltol=1e-10, log=True)
+    (ub, hb), (us, hs_) = out["1"], out["0"]
+    assert hb.iters == hs_.iters and hb.mvps == hs_.mvps
+    rb, rs = hb["resnorm"], hs_["resnorm"]
+    live = rs > 1e-7 * rs[0]                  # (below that the recomputed restart residual is cancellation noise in either sweep)
+    assert np.max((np.abs(rb - rs) / rs)[live]) < 1e-9 and rel_err(ub, us) < 1e-7
+    uo = np.zeros(M.N, complex)
+    uo, ho = o.gmres(uo, A, rhs, restart=restart, maxiter=40, reltol=1e-10)
+    k = min(len(rb), len(ho.resnorm))
+    ref = np.array(ho.resnorm[:k])
+    big = ref > 1e3 * 1e-10 * ref[0]
+    assert abs(hb.iters - ho.iters) <= 1 and np.max(np.abs(rb[:k] - ref)[big] / ref[big]) < 1e-6
+
+
 @pytest.mark.parametrize("orth", ["ModifiedGramSchmidt", "ClassicalGramSchmidt", "DGKS"])
 def test_gmres_converges_true_residual(lsfc, orth):
     c, Mo, M, rhs = _setup(lsfc, "gv16k10")
