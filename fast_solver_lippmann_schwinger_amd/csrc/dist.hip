@@ -175,8 +175,15 @@ void dist_profile_stages(lsfc_plan* p, const cplx* x, cplx* y, std::function<voi
     hipStream_t st = p->stream;
     const int K = d->K;
     // un-overlapped, stage by stage, all on the plan's stream (the production path overlaps the exchanges)
-    add("xfwd", N * (C + 8) + 2 * N * C, [=] { phase1(p, x, true, st); });
     const bool sim = d->sim || d->member;                       // simulated rank: compute stages only (per-rank kernel times at P ranks)
+    if (sim) {
+        // no exchange runs here, so the receive buffer would hold the zeros of plan creation and the y / z / y passes would
+        // transform zeros -- on which this power-limited chip clocks ~9 % higher.  Prime it once with the x pass's own
+        // output (same size: P * K blocks either way), i.e. with data of the statistics the real exchange delivers.
+        phase1(p, x, true, st);
+        LSFC_HIP(hipMemcpyAsync(d->R1.p, d->S1.p, std::min(d->R1.bytes(), d->S1.bytes()), hipMemcpyDeviceToDevice, st));
+    }
+    add("xfwd", N * (C + 8) + 2 * N * C, [=] { phase1(p, x, true, st); });
     if (!sim) add("alltoall_in", 2 * N * C, [=] { for (int c = 0; c < K; ++c) exchange(p, c, false, st); });
     add("yfwd", 6 * N * C, [=] { for (int c = 0; c < K; ++c) phase2_yfwd(p, c, st); });
     add("zfused", 16 * N * C, [=] { for (int c = 0; c < K; ++c) phase2_zfused(p, c, st); });

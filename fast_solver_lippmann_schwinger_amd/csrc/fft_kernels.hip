@@ -447,8 +447,8 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
     // (unsigned: scalar base + zero-extended 32-bit lane offset is an addressing mode of the global instructions)
     const unsigned doff = (unsigned)(li + (int)dLine * t), dstep = (unsigned)((int)dLine * T);      // element j = t + T e of this thread's line
     const unsigned soff = (unsigned)(li + (int)sLine * t), sstep = (unsigned)((int)sLine * T);
-    // (element e of the thread: the uniform part dstep * e goes into the scalar base, the lane's part stays ONE 32-bit offset --
-    // written as (base + dstep * e)[doff]: as base[doff + dstep * e] the 32-bit sum may wrap, so the compiler must add per lane)
+    // (tried in round 3: the uniform part dstep * e of an element index moved into the scalar base, (base + dstep * e)[doff] -- one
+    // lane offset instead of a per-lane add per element: neutral at 1024 points, slower on the 768-point line; not kept)
     constexpr bool MIRG = (XL & 2) != 0;
     [[maybe_unused]] unsigned moff[MIRG ? H : 1];      // MIRG: element index of the mirror entry of slot e + H in this thread's symbol line
     if constexpr (MIRG) {
@@ -460,7 +460,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         cplx* d; const cplx* s;
         locate(cur, d, s);
 #pragma unroll
-        for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? (d + (size_t)dstep * e)[doff] : make_double2(0.0, 0.0);
+        for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? d[doff + dstep * e] : make_double2(0.0, 0.0);
     }
     for (;;) {
         // HALF: draw the next ticket now; it is published and read around the barriers of the symbol multiply below
@@ -477,7 +477,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
             locate(cur, d, s);
             const unsigned so = launder_v(soff);
 #pragma unroll
-            for (int e = 0; e < H; ++e) sv[e] = (s + (size_t)sstep * e)[so];
+            for (int e = 0; e < H; ++e) sv[e] = s[so + sstep * e];
             if constexpr (MIRG) {
 #pragma unroll
                 for (int e = 0; e < H; ++e) smr[e] = s[moff[e]];
@@ -540,7 +540,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
             locate(next, dn, sn);
             const unsigned dof = launder_v(doff);
 #pragma unroll
-            for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? (dn + (size_t)dstep * e)[dof] : make_double2(0.0, 0.0);
+            for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? dn[dof + dstep * e] : make_double2(0.0, 0.0);
         }
         if constexpr (!SPLIT && WS) fft_inverse_ws<C, LL, true, TWL, DEFER, (XL > 0)>(v, t, tw, smem, 0, li);
         else fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
@@ -549,7 +549,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
             locate(cur, d, s);
             const unsigned dof = launder_v(doff);
 #pragma unroll
-            for (int e = 0; e < H; ++e) if (EXACT || t + T * e < nin) (d + (size_t)dstep * e)[dof] = v[e];
+            for (int e = 0; e < H; ++e) if (EXACT || t + T * e < nin) d[dof + dstep * e] = v[e];
         }
         if (!more) break;
         cur = next;

@@ -1,7 +1,7 @@
 """Fluid model of the pipelined slab-distributed apply (csrc/dist.hip) on one rank: x pass -> K chunked exchanges in
 (the link is shared with the exchanges back) -> per-chunk y/z/y passes -> exchanges back -> inverse x pass, with the
 z-half split of the pipeline ends.  Inputs are the measured per-rank kernel times of
-profiles/r01_dist_per_rank_compute_sim.log and the link model of DESIGN.md section 5; the output is what chunk count K
+profiles/r03_dist_per_rank_compute_sim.log and the link model of DESIGN.md section 5; the output is what chunk count K
 the schedule wants at a given link efficiency.  A model to choose defaults before the first multi-GPU run, nothing more.
 
 usage: python tools/pipeline_model.py"""
@@ -37,12 +37,13 @@ def apply_ms(K, eta, link_full, comp_total, pen, x1, x3, dt=0.0005):
 
 
 if __name__ == "__main__":
-    single = 13.55
-    # per rank at 512^3 (ms): x passes, y+z+y passes, chunking penalty by K (measured with simulated ranks), one transpose at
-    # the nominal per-direction link rate
-    cases = {8: dict(x1=0.18, x3=0.21, comp_total=1.53, link_full=0.874, pen={2: -0.02, 4: 0.0, 8: 0.08, 16: 0.16}),
-             4: dict(x1=0.39, x3=0.38, comp_total=2.84, link_full=3.495, pen={2: -0.01, 4: 0.0, 8: 0.05, 16: 0.10}),
-             2: dict(x1=0.70, x3=0.78, comp_total=5.61, link_full=13.98, pen={2: 0.0, 4: 0.0, 8: 0.02, 16: 0.05})}
+    single = 12.33                                            # one GPU, round 3 (profiles/r03_bench_n512.json)
+    # per rank at 512^3 (ms): x passes, y+z+y passes (round 3, simulated ranks with the receive buffers primed with real data:
+    # profiles/r03_dist_per_rank_compute_sim.log), chunking penalty by K (round 1 measurement), one transpose at the nominal
+    # per-direction link rate
+    cases = {8: dict(x1=0.182, x3=0.209, comp_total=1.417, link_full=0.874, pen={2: -0.02, 4: 0.0, 8: 0.08, 16: 0.16}),
+             4: dict(x1=0.380, x3=0.383, comp_total=2.576, link_full=3.495, pen={2: -0.01, 4: 0.0, 8: 0.05, 16: 0.10}),
+             2: dict(x1=0.678, x3=0.760, comp_total=4.989, link_full=13.98, pen={2: 0.0, 4: 0.0, 8: 0.02, 16: 0.05})}
     for P, c in cases.items():
         for eta in (0.7, 0.8, 0.9, 1.0):
             row = {K: apply_ms(K, eta, c["link_full"], c["comp_total"], c["pen"][K], c["x1"], c["x3"]) for K in (2, 4, 8, 16)}
