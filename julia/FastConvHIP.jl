@@ -99,6 +99,15 @@ end
 function LinearAlgebra.mul!(Y::AbstractArray{Complex{Float64},1}, M::FastMHIP, b::AbstractArray{Complex{Float64},1})
     Y[:] = M * b
 end
+# dense vectors (what gmres! hands over): straight into the caller's memory, no temporaries -- at 512^3 the two 2-GB host copies of
+# the generic method above cost more than the apply; Y may alias b
+function LinearAlgebra.mul!(Y::Vector{Complex{Float64}}, M::FastMHIP, b::Vector{Complex{Float64}})
+    check(ccall((:lsfc_apply, liblsfc), Cint, (Ptr{Cvoid}, Ptr{Complex{Float64}}, Ptr{Complex{Float64}}, Cint), M.plan, b, Y, 0))
+    Y
+end
+# page-lock long-lived work vectors of the solver (optional; ~4 ms per 512^3 apply): lsfc_host_register / lsfc_host_unregister
+host_register!(v::Vector{Complex{Float64}}) = (check(ccall((:lsfc_host_register, liblsfc), Cint, (Ptr{Cvoid}, Csize_t), v, sizeof(v))); v)
+host_unregister!(v::Vector{Complex{Float64}}) = (check(ccall((:lsfc_host_unregister, liblsfc), Cint, (Ptr{Cvoid},), v)); v)
 
 # FFTconvolution -- src/FastConvolution.jl:110-154 (nu only in the 2D trapezoidal branch), src/FastConvolution3D.jl:39-63
 function FFTconvolution(M::FastMHIP, b::Array{Complex{Float64},1})
