@@ -413,6 +413,8 @@ void plan_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
             pass2d_xinv(p, vb, 1, alpha, beta, st);
             return;
         }
+        // (round 3, measured slower and removed again -- profiles/r03_experiment_a1_window.log: the x and y passes chunk by chunk over
+        // groups of z planes through one chunk-sized window of A1, hoping the Infinity Cache would absorb the 2 x 4.3 GB of A1 traffic)
         pruned_xfwd(Lx, p->tuning, x, nu, p->A1.p, p->tw[0].p, nlines, Lx, p->pitch1, p->dims[0], st);
         if (p->ndim == 3) {
             const int p1 = p->pitch1, p2 = p->pitch2;
