@@ -11,7 +11,7 @@ typedef double2 cplx;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int MODE>
-__global__ __launch_bounds__(512) void k_probe(cplx* __restrict__ a2, const cplx* __restrict__ sym, int ntx, int Ly, int l, int64_t p2, int64_t zb, int hz) {
+__global__ __launch_bounds__(512) void k_probe(cplx* __restrict__ a2, const cplx* __restrict__ sym, int ntx, int Ly, int l, int64_t p2, int64_t zb, int hz, int64_t out_shift) {
     const int li = threadIdx.x % 8, t = threadIdx.x / 8;
     const unsigned ntiles = (unsigned)ntx * Ly;
     if constexpr (MODE == 2) {
@@ -45,19 +45,24 @@ __global__ __launch_bounds__(512) void k_probe(cplx* __restrict__ a2, const cplx
         }
         return;
     }
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const unsigned per = (ntiles + gridDim.x - 1) / gridDim.x;
+    for (unsigned it = 0; it < per; ++it) {
+        // MODE 5: every workgroup walks over a CONTIGUOUS range of tiles instead of tiles b, b + G, b + 2G, ...
+        const unsigned tile = MODE == 5 ? blockIdx.x * per + it : blockIdx.x + it * gridDim.x;
+        if (tile >= ntiles) break;
         const int row = tile % Ly, xb = tile / Ly;
         cplx* d; int64_t step, off;
-        if (MODE == 0) { d = a2 + (int64_t)xb * p2 * Ly + (int64_t)row * p2; off = li + 8 * t; step = 8 * 64; }                       // [xb][y][z][8]
+        if (MODE != 1) { d = a2 + (int64_t)xb * p2 * Ly + (int64_t)row * p2; off = li + 8 * t; step = 8 * 64; }                       // [xb][y][z][8]
         else { d = a2 + (int64_t)xb * zb * (l / 8) + (int64_t)row * 64; off = li + 8 * (t % 8) + (int64_t)(t / 8) * zb; step = 8 * zb; }   // [xb][z/8][y][z%8][8]
         const cplx* s = sym + ((int64_t)xb * (Ly / 2 + 1) + (row <= Ly / 2 ? row : Ly - row)) * 8 * hz + li + 8 * t;
         cplx v[8], w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = d[off + step * e];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) w[e] = s[8 * 64 * e];
+        for (int e = 0; e < 8; ++e) w[e] = MODE == 3 ? make_double2(1.0, 2.0) : s[8 * 64 * e];
+        cplx* o = MODE == 4 ? d + out_shift : d;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d[off + step * e] = make_double2(v[e].x + w[e].x, v[e].y - w[e].y);
+        for (int e = 0; e < 8; ++e) o[off + step * e] = make_double2(v[e].x + w[e].x, v[e].y - w[e].y);
     }
 }
 
@@ -66,14 +71,14 @@ int main() {
     const int64_t p2 = 8 * l + 72, zb = (int64_t)Ly * 64 + 72;            // (both padded off the power-of-two strides)
     const size_t e2 = (size_t)(p2 * Ly > zb * (l / 8) ? p2 * Ly : zb * (l / 8)) * (Lx / 8), es = (size_t)(Lx / 8) * (Ly / 2 + 1) * 8 * hz;
     cplx *a2, *sym;
-    CK(hipMalloc(&a2, e2 * sizeof(cplx))); CK(hipMalloc(&sym, es * sizeof(cplx)));
-    CK(hipMemset(a2, 0, e2 * sizeof(cplx))); CK(hipMemset(sym, 0, es * sizeof(cplx)));
+    CK(hipMalloc(&a2, 2 * e2 * sizeof(cplx))); CK(hipMalloc(&sym, es * sizeof(cplx)));
+    CK(hipMemset(a2, 0, 2 * e2 * sizeof(cplx))); CK(hipMemset(sym, 0, es * sizeof(cplx)));
     hipEvent_t s, e; CK(hipEventCreate(&s)); CK(hipEventCreate(&e));
     const double gb = (4.0 + 4.0 + 2.0) * 16.0 * (double)n * n * n / 1e9;      // data in + out (4 N complex each), quarter symbol (mirror rows: cache)
     auto time = [&](auto kern, const char* name, int grid = 256) {
-        for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, 0, a2, sym, Lx / 8, Ly, l, p2, zb, hz);
+        for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, 0, a2, sym, Lx / 8, Ly, l, p2, zb, hz, (int64_t)e2);
         hipEventRecord(s, 0);
-        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, 0, a2, sym, Lx / 8, Ly, l, p2, zb, hz);
+        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, 0, a2, sym, Lx / 8, Ly, l, p2, zb, hz, (int64_t)e2);
         hipEventRecord(e, 0); hipEventSynchronize(e);
         float ms = 0; hipEventElapsedTime(&ms, s, e); ms /= 10;
         printf("%-58s %.3f ms  %.2f TB/s of 21.5 GB\n", name, ms, gb / ms);
@@ -88,5 +93,8 @@ int main() {
     time(k_probe<0>, "today's layout, 4 workgroups per CU", 1024);
     time(k_probe<2>, "today's layout, 1 per CU, next tile's loads before the stores");
     time(k_probe<2>, "today's layout, 2 per CU, next tile's loads before the stores", 512);
+    time(k_probe<3>, "today's layout, no symbol stream (17.2 GB)");
+    time(k_probe<4>, "today's layout, stores to a second array (not in place)");
+    time(k_probe<5>, "today's layout, contiguous tile range per workgroup");
     return 0;
 }
