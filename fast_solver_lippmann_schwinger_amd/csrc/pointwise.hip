@@ -638,4 +638,12 @@ void blas_scale_inv_dev(cplx* a, const cplx* s, int64_t n, hipStream_t st) {
 }
 int blas_partial_count() { return RED_BLOCKS * 66; }   // 64 slots of a multidot + two more (norm partials, alternating slots of the fused sweeps)
 
+// loads this translation unit's code object on the current device (pruned.hip: pruned_warmup -- every code object of the library is
+// resident before the first transfer or pass of a process exists; DESIGN 3, "The round-2 first-apply GPU fault")
+__global__ void k_warmup_pointwise(int* p) { if (p) *p = 0; }
+void warmup_pointwise() {
+    hipLaunchKernelGGL(k_warmup_pointwise, dim3(1), dim3(64), 0, 0, (int*)nullptr);
+    LSFC_HIP(hipGetLastError());
+}
+
 } // namespace lsfc

@@ -19,6 +19,7 @@
 // The whole sequence SpMV -> L solve -> U solve -> scatter is captured once in a hipGraph on fixed internal buffers
 // and replayed per apply.
 #include "common.hpp"
+#include "pruned.hpp"
 #include <algorithm>
 #include <complex>
 #include <cstring>
@@ -508,6 +509,14 @@ static void precond_apply_dev(lsfc_precond* pc, cplx* v, hipStream_t st) {
     LSFC_HIP(hipMemcpyAsync(v, pc->vout.p, bytes, hipMemcpyDeviceToDevice, st));
 }
 
+// loads this translation unit's code object on the current device (pruned.hip: pruned_warmup -- every code object of the library is
+// resident before the first transfer or pass of a process exists; DESIGN 3, "The round-2 first-apply GPU fault")
+__global__ void k_warmup_precond(int* p) { if (p) *p = 0; }
+void warmup_precond() {
+    hipLaunchKernelGGL(k_warmup_precond, dim3(1), dim3(64), 0, 0, (int*)nullptr);
+    LSFC_HIP(hipGetLastError());
+}
+
 } // namespace lsfc
 
 using namespace lsfc;
@@ -527,6 +536,7 @@ int lsfc_precond_create(lsfc_precond** out, int64_t N,
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) fail(LSFC_ENODEV, "no HIP device available: the preconditioner apply has no CPU fallback");
         LSFC_REQUIRE(device >= 0 && device < count, "device %d out of range (have %d)", device, count);
         LSFC_HIP(hipSetDevice(device));
+        pruned_warmup(device);                             // every code object of the library resident before any work of this process is queued
         std::unique_ptr<lsfc_precond> pc(new lsfc_precond());
         pc->device = device; pc->N = N;
         // As: CSR, 32-bit columns on the device

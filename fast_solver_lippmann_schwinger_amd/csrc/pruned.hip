@@ -19,6 +19,7 @@ namespace lsfc {
     void pruned_warmup_f##F();                                                                                         \
     int pruned_twfull_len_f##F(int);                                                                                            \
     void pruned_twfull_f##F(int, const cplx*, cplx*);
+void warmup_pointwise(); void warmup_symbol(); void warmup_precond();      // pointwise.hip, symbol.hip, precond.hip
 LSFC_FAMILY_DECLS(2)
 LSFC_FAMILY_DECLS(3)
 LSFC_FAMILY_DECLS(5)
@@ -42,6 +43,7 @@ void pruned_warmup(int device) {
     // LSFC_EAGER_LOAD=0 (developer switch, diagnostics only): leave the code objects to HIP's lazy loading at first launch
     if (const char* e = getenv("LSFC_EAGER_LOAD")) if (e[0] == '0') return;
     pruned_warmup_f2(); pruned_warmup_f3(); pruned_warmup_f5();
+    warmup_pointwise(); warmup_symbol(); warmup_precond();
     LSFC_HIP(hipDeviceSynchronize());
     done.insert(device);
 }

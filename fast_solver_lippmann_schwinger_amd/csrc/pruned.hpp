@@ -34,7 +34,7 @@ struct PrunedTuning {
 };
 
 bool pruned_length_supported(int64_t L);
-// load the kernels' code objects on `device` (current device) once, ahead of the first pass (see fft_kernels.hip)
+// load EVERY code object of the library on `device` (the current device) once, ahead of the first transfer or pass (fft_kernels.hip)
 void pruned_warmup(int device);
 // smallest supported line length L >= max(2n, 32): L = 2^k, 3 * 2^k or 5 * 2^k (0: none up to 2048)
 int pruned_best_length(int64_t n);

@@ -334,4 +334,12 @@ void symbol_trap2d_literal(lsfc_plan* p, double x0, double y0, double h, cplx d0
     LSFC_HIP(hipStreamSynchronize(p->stream));
 }
 
+// loads this translation unit's code object on the current device (pruned.hip: pruned_warmup -- every code object of the library is
+// resident before the first transfer or pass of a process exists; DESIGN 3, "The round-2 first-apply GPU fault")
+__global__ void k_warmup_symbol(int* p) { if (p) *p = 0; }
+void warmup_symbol() {
+    hipLaunchKernelGGL(k_warmup_symbol, dim3(1), dim3(64), 0, 0, (int*)nullptr);
+    LSFC_HIP(hipGetLastError());
+}
+
 } // namespace lsfc
