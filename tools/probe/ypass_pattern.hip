@@ -43,6 +43,39 @@ __global__ __launch_bounds__(512) void k_probe(const cplx* __restrict__ a1, cplx
     }
 }
 
+
+// Wider workgroups (round 3): 1024 threads moving either 16 x' lines of one plane (256-B chunks on the A1 side, two A2 tiles) or 8 x'
+// lines of TWO consecutive planes (128-B chunks from two planes, 256-B runs on the A2 side) -- what LINES = 16 in the y passes would buy
+template <int SHAPE, bool INV>
+__global__ __launch_bounds__(1024) void k_probe_wide(const cplx* __restrict__ a1, cplx* __restrict__ a2, int Lx, int m, int l, int Ly, int p1, int64_t p2) {
+    const int TG = 32, TZ = 8;
+    const int xi = threadIdx.x % 16, t = threadIdx.x / 16;
+    // SHAPE 0: xi = 16 x'; the grid covers (Lx / 16) groups x l planes.  SHAPE 1: xi = (z parity, 8 x'); (Lx / 8) groups x (l / 2) plane pairs
+    const int ngrp = SHAPE == 0 ? Lx / 16 : Lx / 8, nz = SHAPE == 0 ? l : l / 2;
+    const int tg = SHAPE == 0 ? TG / 2 : TG, tz = SHAPE == 0 ? TZ : TZ / 2;
+    const int within = blockIdx.x % (tg * tz), tile = blockIdx.x / (tg * tz);
+    const int ntg = ngrp / tg;
+    const int g = (tile % ntg) * tg + within % tg, zz = (tile / ntg) * tz + within / tg;
+    (void)nz;
+    const int xp = SHAPE == 0 ? g * 16 + xi : g * 8 + (xi % 8);
+    const int z = SHAPE == 0 ? zz : 2 * zz + xi / 8;
+    const int xb = xp / 8, xq = xp % 8;
+    cplx* r1 = const_cast<cplx*>(a1) + xp + (int64_t)p1 * m * z;
+    cplx v[16];
+    auto a2at = [&](int y) -> cplx* { return a2 + xq + (int64_t)8 * z + p2 * ((int64_t)Ly * xb + y); };
+    if (!INV) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = r1[(int64_t)p1 * (t + 64 * e)];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) *a2at(t + 64 * e) = v[e % 8];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = *a2at(t + 64 * e);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r1[(int64_t)p1 * (t + 64 * e)] = make_double2(v[e].x + v[e + 8].x, v[e].y + v[e + 8].y);
+    }
+}
+
 int main() {
     const int n = 512, Lx = 1024, Ly = 1024, m = n, l = n, p1 = Lx + 40;
     const int64_t p2 = 8 * l + 72;
@@ -66,6 +99,19 @@ int main() {
     time(k_probe<2, false>, "yfwd: A1 side contiguous, A2 as today");
     time(k_probe<3, false>, "yfwd: A1 as today, A2 side contiguous");
     time(k_probe<4, false>, "yfwd shape, both sides contiguous (copy)");
+    auto timew = [&](auto kern, const char* name) {
+        const dim3 gw((Lx / 16) * l), bw(1024);
+        for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, gw, bw, 0, 0, a1, a2, Lx, m, l, Ly, p1, p2);
+        hipEventRecord(s, 0);
+        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, gw, bw, 0, 0, a1, a2, Lx, m, l, Ly, p1, p2);
+        hipEventRecord(e, 0); hipEventSynchronize(e);
+        float ms = 0; hipEventElapsedTime(&ms, s, e); ms /= 10;
+        printf("%-44s %.3f ms  %.2f TB/s\n", name, ms, gb / ms);
+    };
+    timew(k_probe_wide<0, false>, "yfwd pattern, 16 x' per workgroup");
+    timew(k_probe_wide<1, false>, "yfwd pattern, 8 x' x 2 planes per workgroup");
+    timew(k_probe_wide<0, true>, "yinv pattern, 16 x' per workgroup");
+    timew(k_probe_wide<1, true>, "yinv pattern, 8 x' x 2 planes per workgroup");
     time(k_probe<0, true>, "yinv pattern, layout [xb][y][z][8] (today)");
     time(k_probe<1, true>, "yinv pattern, layout [xb][z/8][y][z%8][8]");
     time(k_probe<2, true>, "yinv: A1 side contiguous, A2 as today");
