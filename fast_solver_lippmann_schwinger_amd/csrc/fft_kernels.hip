@@ -690,8 +690,8 @@ template <class C, bool SPLIT, bool LATE_SYM = false, bool TICKETS = false> stat
         lds += (size_t)C::TWLEN * sizeof(cplx);
         tw = twl;
     }
-    // lane exchange between the two radix-8 stages (ticketed whole tiles, symbol after the first stage: the 512^3 form)
-    if constexpr (xlane_ok<C, LL>() && LATE_SYM && TICKETS) {
+    // lane exchange between the two radix-8 stages (whole tiles, symbol after the first stage: the 512^3 and 256^3 forms)
+    if constexpr (xlane_ok<C, LL>() && LATE_SYM) {
         if (xl == 1) {
             if (twl) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, 1> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, 1>;
             else     k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false, LATE_SYM, false, TICKETS, 1> : k_zfused_persist<C, LINES, SPLIT, false, false, LATE_SYM, false, TICKETS, 1>;
@@ -902,7 +902,7 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
                 LSFC_HIP(hipGetLastError());
                 return;
             }
-            if ((zp == 3 || zp == 6) && !split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
+            if ((zp == 3 || zp == 6) && !split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, tn.xlane < 0 ? 1 : tn.xlane))); }
             else if (zp >= 3) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
             else if (split) { LSFC_DISPATCH_L(L, (zfused_persist_t<C, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }
             else       { LSFC_DISPATCH_L(L, (zfused_persist_t<C, false>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st))); }

@@ -447,6 +447,21 @@ def test_host_vector_pipeline(lsfc, K, monkeypatch):
     assert rel_err(lsfc.FFTconvolution(M, b), o.convolve_reduced(G2, b, (n, m, l))) < TOL
 
 
+def test_first_apply_of_a_fresh_process(lsfc):
+    # The first host-vector apply of a PROCESS is where round 2's intermittent GPU fault sat: a staged
+    # asynchronous copy in flight while the first launch loaded a code object.  The library now loads every code object at the
+    # first plan creation.  One child process, one plan (the 2D trapezoidal n = 21 case of that fault), one apply; run once.
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("LSFC_EAGER_LOAD", "LSFC_HOST_COPY", "AMD_LOG_LEVEL"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "first_apply_trace.py"), "test"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "plan: pruned-hip (48, 48, 1)" in r.stdout and "finite: True repeatable: True" in r.stdout
+
+
 def test_device_resident_vectors_torch(lsfc):
     import torch
     c = cases.case_3d("gv16")
