@@ -634,6 +634,10 @@ template <bool HALF> __device__ __forceinline__ void ticket_decode(unsigned w, u
     else { tile = 2u * ((w & 7u) + 8u * (w >> 4)) + ((w >> 3) & 1u); half = 0u; }
 }
 
+// Pairs (round 3): a work item is a PAIR of whole tiles, 2 p and 2 p + 1 with p = q + 8 c -- a row and its mirror row, processed one
+// after the other by the SAME workgroup, which keeps the symbol values they share in registers (ntiles / 16 pairs per queue)
+__device__ __forceinline__ unsigned ticket_decode_pair(unsigned w, unsigned sub) { return 2u * ((w & 7u) + 8u * (w >> 3)) + sub; }
+
 // Host mirror of the slot bookkeeping: frequency index held at storage index s.
 // After the last stage slot e = u + NB*q of thread t sits at position (t + T*u)*RL + q; in-place DIF leaves
 // frequency k = k0 + R0*(k1 + R1*(k2 + R2*k3)) at position k0*M0 + k1*M1 + k2*M2 + k3 (M_s = L / (R0..R_s)).

@@ -399,6 +399,10 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
     constexpr bool DEFER = false;
 #endif
     const int li = threadIdx.x % LINES, t = threadIdx.x / LINES;
+    // XL & 4 (PAIR; ticketed whole tiles): a work item is a row pair -- the tile of a row and of its mirror row, which multiply by the
+    // same symbol values -- and the workgroup runs the two tiles back to back with ONE load of those values: they stay in registers
+    // across the first tile's inverse transform and the second tile's forward transform (8 of the 24 loads of every second tile go)
+    constexpr bool PAIR = (XL & 4) != 0 && TICKETS && !HALF;
     // work item: a tile (static walk b, b + G, ...) or, HALF, a ticket of this workgroup's XCD
     // (HALF: a work item is (ticket << 3 | queue); DONE = nothing left anywhere)
     constexpr unsigned DONE = 0xFFFFFFFFu;
@@ -416,7 +420,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
     };
     if constexpr (TICKETS) {
         queue = xcc_id();
-        nwork = HALF ? ntiles / 4 : ntiles / 8;         // (ntiles / 8 tiles per queue) [x 2 halves]; the host checks ntiles % 16 == 0
+        nwork = HALF ? ntiles / 4 : (PAIR ? ntiles / 16 : ntiles / 8);   // (ntiles / 8 tiles per queue) [x 2 halves | as pairs]; the host checks ntiles % 16 == 0
         slot = reinterpret_cast<unsigned*>(smem + persist_lds_bytes<C, LINES, SPLIT, TWL, HALF>());
         if (threadIdx.x == 0) *slot = draw();
         __syncthreads();
@@ -434,10 +438,11 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
     // 64-bit per-thread pointers kept across the loop cost the registers that decide between "fits" and "spills", and a
     // spill reload at the loop top would make the wave wait for the previous tile's stores (scratch and global memory
     // share the in-order vmcnt counter).
-    auto locate = [&](unsigned w, cplx*& dbase, const cplx*& sbase) {
+    auto locate = [&](unsigned w, cplx*& dbase, const cplx*& sbase, unsigned sub = 0) {
         unsigned tl_ = w; int half = 0;
         // (ticket -> tile, half: fft_core.hpp ticket_decode)
-        if constexpr (TICKETS) { unsigned hf; ticket_decode<HALF>(w, tl_, hf); half = (int)hf * LINES; }
+        if constexpr (PAIR) tl_ = ticket_decode_pair(w, sub);
+        else if constexpr (TICKETS) { unsigned hf; ticket_decode<HALF>(w, tl_, hf); half = (int)hf * LINES; }
         const int o = (int)(tl_ % (unsigned)nouter), g = (int)(tl_ / (unsigned)nouter);
         int outer = o, srow = o;
         if (ytab) { const int2 e2 = ytab[o]; outer = e2.x; srow = e2.y; }
@@ -462,19 +467,29 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
 #pragma unroll
         for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? d[doff + dstep * e] : make_double2(0.0, 0.0);
     }
+    [[maybe_unused]] unsigned sub = 0;                  // PAIR: which tile of the pair `cur` is being processed
+    [[maybe_unused]] const cplx* sheld = nullptr;       // PAIR: the symbol tile whose values sv_pair / smid_pair hold
+    [[maybe_unused]] cplx sv_pair[PAIR ? H : 1];        // PAIR: the symbol values live across the two tiles of a pair (loop-carried registers)
+    [[maybe_unused]] cplx smid_pair = make_double2(0.0, 0.0);
     for (;;) {
         // HALF: draw the next ticket now; it is published and read around the barriers of the symbol multiply below
         unsigned drawn = 0;
-        if constexpr (TICKETS) { if (threadIdx.x == 0) drawn = draw(); }
+        if constexpr (TICKETS) { if (threadIdx.x == 0 && (!PAIR || sub == 0)) drawn = draw(); }
         cplx v[E];
 #pragma unroll
         for (int e = 0; e < H; ++e) { v[e] = nd[e]; v[e + H] = make_double2(0.0, 0.0); }
-        cplx sv[H];
+        cplx sv_tile[PAIR ? 1 : H];
+        cplx (&sv)[H] = *reinterpret_cast<cplx (*)[H]>(PAIR ? &sv_pair[0] : &sv_tile[0]);
         [[maybe_unused]] cplx smr[MIRG ? H : 1];
-        cplx smid = make_double2(0.0, 0.0);
+        cplx smid_tile = make_double2(0.0, 0.0);
+        cplx& smid = PAIR ? smid_pair : smid_tile;
         auto load_symbol = [&] {
             cplx* d; const cplx* s;
-            locate(cur, d, s);
+            locate(cur, d, s, sub);
+            if constexpr (PAIR) {
+                if (s == sheld) return;                 // (uniform) the mirror row's tile: same symbol values, already in registers
+                sheld = s;
+            }
             const unsigned so = launder_v(soff);
 #pragma unroll
             for (int e = 0; e < H; ++e) sv[e] = s[so + sstep * e];
@@ -520,7 +535,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
 #pragma unroll
         for (int e = 0; e < H; ++e) stage[(t + T * e) * LINES + li] = sv[e];
         if (t == 0) stage[(C::L / 2) * LINES + li] = smid;
-        if constexpr (TICKETS) { if (threadIdx.x == 0) *slot = drawn; }
+        if constexpr (TICKETS) { if (threadIdx.x == 0 && (!PAIR || sub == 0)) *slot = drawn; }
         LSFC_BARRIER();
         {
             const int* zmt = launder_s(zm) + t;            // (re-read per tile from L1: eight registers less across the loop)
@@ -534,10 +549,11 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         if constexpr (TICKETS) next = __builtin_amdgcn_readfirstlane(*slot);
         LSFC_BARRIER();
         }
-        const bool more = TICKETS ? next != DONE : next < nwork;
+        // PAIR: after the first tile of a pair comes its second; the drawn ticket (in the slot since the first tile) is for afterwards
+        const bool more = PAIR ? (sub == 0 || next != DONE) : (TICKETS ? next != DONE : next < nwork);
         if (more) {
             cplx* dn; const cplx* sn;
-            locate(next, dn, sn);
+            if (PAIR && sub == 0) locate(cur, dn, sn, 1u); else locate(next, dn, sn, 0u);
             const unsigned dof = launder_v(doff);
 #pragma unroll
             for (int e = 0; e < H; ++e) nd[e] = (EXACT || t + T * e < nin) ? dn[dof + dstep * e] : make_double2(0.0, 0.0);
@@ -546,13 +562,14 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         else fft_inverse<C, LL, true, TWL>(v, t, tw, smem, 0, li);
         {
             cplx* d; const cplx* s;
-            locate(cur, d, s);
+            locate(cur, d, s, sub);
             const unsigned dof = launder_v(doff);
 #pragma unroll
             for (int e = 0; e < H; ++e) if (EXACT || t + T * e < nin) d[dof + dstep * e] = v[e];
         }
         if (!more) break;
-        cur = next;
+        if constexpr (PAIR) { if (sub == 0) sub = 1; else { sub = 0; cur = next; } }
+        else cur = next;
     }
 }
 
@@ -697,7 +714,8 @@ template <class C, bool SPLIT, bool LATE_SYM = false, bool TICKETS = false> stat
             else     k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false, LATE_SYM, false, TICKETS, 1> : k_zfused_persist<C, LINES, SPLIT, false, false, LATE_SYM, false, TICKETS, 1>;
         } else if (xl >= 2 && twl) {
             // 3: + mirror symbol values from L2 (XL & 2; measured slower, profiles/r03_experiment_fused_pass_variants.log)
-            if (xl == 3) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, 3> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, 3>;
+            if (xl == 5 && TICKETS) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, 5> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, 5>;
+            else if (xl == 3) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, 3> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, 3>;
             else k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, 1> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, 1>;
         }
     }
@@ -898,7 +916,7 @@ void FAM(pruned_zfused)(int L, const PrunedTuning& tn, cplx* data, const cplx* s
             }
             // 6: whole tiles (as 3) handed out by tickets in row pairs per XCD
             if (zp == 6 && !split && ((int64_t)(Lx / XB) * nouter) % 16 == 0 && nouter % 2 == 0) {
-                LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, tn.xlane < 0 ? 1 : tn.xlane)));
+                LSFC_DISPATCH_L(L, (zfused_persist_t<C, false, true, true>(data, sym, tw, tn.tw_lds ? twl : nullptr, Lx, nouter, dTile, dOuter, dLine, sTile, sOuter, sLine, ytab, zm, nin, st, tn.xlane < 0 ? 5 : tn.xlane)));
                 LSFC_HIP(hipGetLastError());
                 return;
             }

@@ -243,7 +243,7 @@ def test_fused_pass_forms_even_symbol_long_z_lines(lsfc, L, short):
     for form in (0, 3, 5, 6):
         # xlane: the exchange between the two radix-8 stages of the 1024- and 1536-point lines through the lanes of the
         # wavefront (forms 5 and 6) or through LDS
-        for xl in (3, 1, 0):
+        for xl in (5, 3, 1, 0):
             M.set_tuning(z_persist=form, xlane=xl)
             got[form] = M * b
             assert rel_err(got[form], want) < TOL, (form, xl)

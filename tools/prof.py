@@ -24,6 +24,7 @@ VARIANTS = [("auto (persistent pipelined z pass)", {}, {}),
             ("whole tiles by tickets, LDS exchanges only", {}, dict(z_persist=6, xlane=0)),
             ("whole tiles, lane exchange", {}, dict(z_persist=6, xlane=1)),
             ("whole tiles, lane exchange + mirror symbol from L2", {}, dict(z_persist=6, xlane=3)),
+            ("whole tiles, lane exchange + row pairs share the symbol registers", {}, dict(z_persist=6, xlane=5)),
 
             ("half tiles by tickets, LDS exchanges only", {}, dict(z_persist=5, xlane=0))]
 if os.environ.get("PROF_ONLY"):
