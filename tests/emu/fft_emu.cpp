@@ -287,6 +287,16 @@ int main() {
         for (unsigned t = 0; t < ntiles; ++t) for (int hf = 0; hf <= half; ++hf) if (seen[(size_t)t * 2 + hf] != 1) ++bad;
         if (!half) for (unsigned t = 0; t < ntiles; ++t) if (seen[(size_t)t * 2 + 1] != 0) ++bad;
     }
+    // row pairs as work items (ticket_decode_pair): tiles 2 p, 2 p + 1 of pair p = q + 8 c; every tile exactly once
+    for (unsigned ntiles = 16; ntiles <= 16 * 40; ntiles += 16) {
+        std::vector<int> seen(ntiles, 0);
+        for (unsigned q = 0; q < 8; ++q) for (unsigned c = 0; c < ntiles / 16; ++c) for (unsigned sub = 0; sub < 2; ++sub) {
+            const unsigned tile = ticket_decode_pair((c << 3) | q, sub);
+            if (tile >= ntiles || (tile & 1u) != sub) { ++bad; continue; }
+            ++seen[tile];
+        }
+        for (unsigned t = 0; t < ntiles; ++t) if (seen[t] != 1) ++bad;
+    }
     printf("ticket decode / lane exchange checks failed: %d\n", bad);
     if (bad) worst = 1.0;
     // the 1024-point line in 8 interleaved lines (the z pass at 512^3) must have its radix-8 <-> radix-8 exchange local
