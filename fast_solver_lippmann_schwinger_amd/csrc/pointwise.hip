@@ -501,7 +501,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_mgs_block(cplx* __restrict__ w,
     for (int j = 0; j < MB; ++j) ad[j] = make_double2(0.0, 0.0);
 #pragma unroll
     for (int j = 0; j < NP; ++j) ag[j] = make_double2(0.0, 0.0);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // two elements per thread and trip (i and i + stride): twice the loads in flight per wave
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    auto element = [&](int64_t i) {
         cplx x = w[i];
         if (mp > 0) {
 #pragma unroll
@@ -533,6 +535,10 @@ __global__ __launch_bounds__(RED_THREADS) void k_mgs_block(cplx* __restrict__ w,
         } else {
             ad[0].x = fma(x.x, x.x, fma(x.y, x.y, ad[0].x));            // after the last block: |w|^2
         }
+    };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 2 * stride) {
+        element(i);
+        if (i + stride < n) element(i + stride);
     }
 #pragma unroll
     for (int q = 0; q < MB + NP; ++q) {
