@@ -115,6 +115,48 @@ def test_sizes_that_are_not_powers_of_two_3d(lsfc, dims):
     assert Mr.pipeline == "rocfft-reduced" and rel_err(Mr * b, ref) < TOL
 
 
+def _random_shapes(seed, count, ndim, lo, hi):
+    rng = np.random.default_rng(seed)
+    return [tuple(int(v) for v in rng.integers(lo, hi + 1, size=ndim)) for _ in range(count)]
+
+
+@pytest.mark.parametrize("dims", _random_shapes(2025, 16, 3, 1, 44) + [(1, 1, 1), (2, 1, 1), (1, 40, 1), (44, 1, 2), (5, 7, 3)])
+def test_random_shapes_3d(lsfc, dims):
+    # seeded random (n, m, l) in 1 .. 44, and degenerate ones: whatever pipeline the plan picks (hand-written lines zero-extended
+    # in registers, or rocFFT on the exact 2n grid where the embedding would cost too much), apply and bare convolution against
+    # the oracle on the reduced grid, host and device vectors, twice (plan state)
+    import torch
+    n, m, l = dims
+    rng = np.random.default_rng(n * 10007 + m * 101 + l)
+    G2 = rng.standard_normal((2 * n, 2 * m, 2 * l)) + 1j * rng.standard_normal((2 * n, 2 * m, 2 * l))
+    nu = rng.uniform(-0.3, 0.3, n * m * l)
+    b = rng.standard_normal(n * m * l) + 1j * rng.standard_normal(n * m * l)
+    M = lsfc.FastM3D(np.fft.fftshift(G2), nu, 2 * n, 2 * m, 2 * l, n, m, l, 3.0)
+    ref = o.apply_reduced(G2, nu, 3.0, b, (n, m, l))
+    y = M * b
+    assert rel_err(y, ref) < TOL, M.pipeline
+    assert np.array_equal(M * b, y)
+    assert rel_err(lsfc.FFTconvolution(M, b), o.convolve_reduced(G2, b, (n, m, l))) < TOL
+    xd = torch.from_numpy(b).cuda(); yd = torch.empty_like(xd)
+    M.mul_(yd, xd)
+    assert np.array_equal(yd.cpu().numpy(), y)
+    M.close()
+
+
+@pytest.mark.parametrize("dims", _random_shapes(7, 12, 2, 1, 300) + [(1, 1), (1, 257), (300, 1), (2, 2)])
+def test_random_shapes_2d(lsfc, dims):
+    n, m = dims
+    rng = np.random.default_rng(n * 1009 + m)
+    G2 = rng.standard_normal((2 * n, 2 * m)) + 1j * rng.standard_normal((2 * n, 2 * m))
+    nu = rng.uniform(-0.3, 0.3, n * m)
+    b = rng.standard_normal(n * m) + 1j * rng.standard_normal(n * m)
+    M = lsfc.FastM(np.fft.fftshift(G2), nu, 2 * n, 2 * m, n, m, 2.0, quadRule="Greengard_Vico")
+    y = M * b
+    assert rel_err(y, o.apply_reduced(G2, nu, 2.0, b, (n, m))) < TOL, M.pipeline
+    assert np.array_equal(M * b, y)
+    M.close()
+
+
 @pytest.mark.parametrize("dims", [(6, 16, 16), (4, 32, 32), (16, 6, 32)])
 def test_builder_3d_tiny_axis_next_to_long_ones(lsfc, dims):
     # an axis of fewer than 8 points would need a working line (32) longer than the literal 4n lattice the slab-wise
