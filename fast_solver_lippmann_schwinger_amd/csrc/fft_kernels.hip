@@ -372,9 +372,11 @@ template <class C, int LINES, bool SPLIT, bool TWL, bool HALF> constexpr size_t 
     return (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes() + (TWL ? (size_t)C::TWLEN * sizeof(cplx) : 0);
 }
 // TICKETS without HALF: whole tiles handed out the same way, in pairs (row, mirror row) per XCD queue.
-// XL: the exchange between the two radix-8 stages of the line runs through the lanes of the wavefront (fft_core.hpp:
-// xlane_transpose8) instead of LDS -- one LDS exchange and two workgroup barriers less per direction.
-// XL & 2: in addition the mirror values of the z-even symbol (slots e >= E/2: the entry of frequency L - kz) are loaded by the
+// XL (round 3) is a set of bits, chosen by the run-time knob "xlane" (0, 1, 3, 5; -1 = 5 where available, else 1):
+// XL & 1: the exchange between the two radix-8 stages of the line runs through the lanes of the wavefront (fft_core.hpp:
+// xlane_transpose8) instead of LDS -- one LDS exchange and two workgroup barriers less per direction (-0.28 ms at 512^3).
+// XL & 4: work items are row PAIRS whose shared symbol values stay in registers (see PAIR below; -0.05 ms).
+// XL & 2 (measured slower, kept for A/B runs): in addition the mirror values of the z-even symbol (slots e >= E/2: the entry of frequency L - kz) are loaded by the
 // thread that needs them, a second read of lines this workgroup fetches anyway (L2 hits), instead of being staged through
 // LDS by the threads that hold them: 8 ds_write_b128 + 8 ds_read_b128 per thread and one of the two barriers around them go.
 template <class C, int LINES, bool SPLIT, bool EXACT, bool TWL, bool LATE_SYM = false, bool HALF = false, bool TICKETS = HALF, int XL = 0>
