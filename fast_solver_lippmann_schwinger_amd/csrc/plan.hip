@@ -485,6 +485,7 @@ HostPipe::~HostPipe() {
     for (hipEvent_t e : ev_up) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_down) (void)hipEventDestroy(e);
     if (ev_free) (void)hipEventDestroy(ev_free);
+    for (hipEvent_t e : { ev_xfree[0], ev_xfree[1], ev_yfree[0], ev_yfree[1] }) if (e) (void)hipEventDestroy(e);
     if (up) (void)hipStreamDestroy(up);
     if (down) (void)hipStreamDestroy(down);
 }
@@ -509,20 +510,26 @@ static int host_pipeline_chunks(const lsfc_plan* p) {
     return 1;
 }
 
-static void host_pipelined_convolve(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double alpha, double beta, int K) {
+// nrhs right-hand sides through the pipeline with TWO staging slots: while right-hand side j is transformed back and its chunks leave
+// for the host, the chunks of right-hand side j + 1 arrive -- across right-hand sides the two PCIe directions do overlap (with
+// page-locked caller vectors; the runtime stages pageable downloads synchronously, which serialises them again).
+static void host_pipelined_convolve(lsfc_plan* p, const cplx* x, cplx* y, int64_t nrhs, bool use_nu, double alpha, double beta, int K) {
     if (!p->hostpipe) {
         std::unique_ptr<HostPipe> hp(new HostPipe());
         LSFC_HIP(hipStreamCreateWithFlags(&hp->up, hipStreamNonBlocking));
         LSFC_HIP(hipStreamCreateWithFlags(&hp->down, hipStreamNonBlocking));
         LSFC_HIP(hipEventCreateWithFlags(&hp->ev_free, hipEventDisableTiming));
+        for (hipEvent_t* e : { &hp->ev_xfree[0], &hp->ev_xfree[1], &hp->ev_yfree[0], &hp->ev_yfree[1] }) LSFC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         p->hostpipe = std::move(hp);
     }
     HostPipe* hp = p->hostpipe.get();
-    while ((int)hp->ev_up.size() < K) {
+    while ((int)hp->ev_up.size() < 2 * K) {
         hipEvent_t a, b;
         LSFC_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming)); hp->ev_up.push_back(a);
         LSFC_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming)); hp->ev_down.push_back(b);
     }
+    const int slots = nrhs > 1 ? 2 : 1;
+    if (p->xs.n < (size_t)(slots * p->N)) { LSFC_HIP(hipStreamSynchronize(p->stream)); p->xs.alloc((size_t)(slots * p->N)); p->ys.alloc((size_t)(slots * p->N)); }
     const double* nu = use_nu ? p->nu.p : nullptr;
     hipStream_t st = p->stream;
     const int Lx = p->pads[0], Ly = p->pads[1], Lz = p->pads[2];
@@ -532,25 +539,36 @@ static void host_pipelined_convolve(lsfc_plan* p, const cplx* x, cplx* y, bool u
     // the staging buffers may still be read by work queued earlier on the plan's stream (device-memory calls are asynchronous)
     LSFC_HIP(hipEventRecord(hp->ev_free, st));
     LSFC_HIP(hipStreamWaitEvent(hp->up, hp->ev_free, 0));
-    for (int c = 0; c < K; ++c) {
-        const int64_t off = c * chunk;
-        LSFC_HIP(hipMemcpyAsync(p->xs.p + off, x + off, (size_t)chunk * sizeof(cplx), hipMemcpyHostToDevice, hp->up));
-        LSFC_HIP(hipEventRecord(hp->ev_up[c], hp->up));
-        LSFC_HIP(hipStreamWaitEvent(st, hp->ev_up[c], 0));
-        cplx* a1 = p->A1.p + (int64_t)c * lines * p1;
-        pruned_xfwd(Lx, p->tuning, p->xs.p + off, nu ? nu + off : nullptr, a1, p->tw[0].p, lines, Lx, p1, n, st);
-        pruned_yfwd(Ly, p->tuning, a1, p->A2.p + (int64_t)8 * c * lz, p->tw[1].p, Lx, m, lz, p1, p2, st);
-    }
-    pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, p->twl[2].p, Lx, Ly,
-                  (int64_t)p2 * Ly, (int64_t)p2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p, p->zmirror.p, l, st);
-    for (int c = 0; c < K; ++c) {
-        const int64_t off = c * chunk;
-        cplx* a1 = p->A1.p + (int64_t)c * lines * p1;
-        pruned_yinv(Ly, p->tuning, p->A2.p + (int64_t)8 * c * lz, a1, p->tw[1].p, Lx, m, lz, p1, p2, st);
-        pruned_xinv(Lx, p->tuning, a1, p->xs.p + off, p->ys.p + off, alpha, beta, p->tw[0].p, lines, Lx, p1, n, st);
-        LSFC_HIP(hipEventRecord(hp->ev_down[c], st));
-        LSFC_HIP(hipStreamWaitEvent(hp->down, hp->ev_down[c], 0));
-        LSFC_HIP(hipMemcpyAsync(y + off, p->ys.p + off, (size_t)chunk * sizeof(cplx), hipMemcpyDeviceToHost, hp->down));
+    for (int64_t j = 0; j < nrhs; ++j) {
+        const int sl = (int)(j % slots);
+        const cplx* xj = x + j * p->N; cplx* yj = y + j * p->N;
+        cplx* xs = p->xs.p + (int64_t)sl * p->N; cplx* ys = p->ys.p + (int64_t)sl * p->N;
+        // slot sl was last used by right-hand side j - 2: its inverse x pass (which reads xs) and its downloads (which read ys) must be over
+        if (j >= slots) { LSFC_HIP(hipStreamWaitEvent(hp->up, hp->ev_xfree[sl], 0)); LSFC_HIP(hipStreamWaitEvent(st, hp->ev_yfree[sl], 0)); }
+        for (int c = 0; c < K; ++c) {
+            const int64_t off = c * chunk;
+            hipEvent_t ev = hp->ev_up[(size_t)(sl * K + c)];
+            LSFC_HIP(hipMemcpyAsync(xs + off, xj + off, (size_t)chunk * sizeof(cplx), hipMemcpyHostToDevice, hp->up));
+            LSFC_HIP(hipEventRecord(ev, hp->up));
+            LSFC_HIP(hipStreamWaitEvent(st, ev, 0));
+            cplx* a1 = p->A1.p + (int64_t)c * lines * p1;
+            pruned_xfwd(Lx, p->tuning, xs + off, nu ? nu + off : nullptr, a1, p->tw[0].p, lines, Lx, p1, n, st);
+            pruned_yfwd(Ly, p->tuning, a1, p->A2.p + (int64_t)8 * c * lz, p->tw[1].p, Lx, m, lz, p1, p2, st);
+        }
+        pruned_zfused(Lz, p->tuning, p->A2.p, p->sym.p, p->tw[2].p, p->twl[2].p, Lx, Ly,
+                      (int64_t)p2 * Ly, (int64_t)p2, 8, (int64_t)8 * p->sym_hz * p->sym_rows, (int64_t)8 * p->sym_hz, 8, p->ytab.p, p->zmirror.p, l, st);
+        for (int c = 0; c < K; ++c) {
+            const int64_t off = c * chunk;
+            hipEvent_t ev = hp->ev_down[(size_t)(sl * K + c)];
+            cplx* a1 = p->A1.p + (int64_t)c * lines * p1;
+            pruned_yinv(Ly, p->tuning, p->A2.p + (int64_t)8 * c * lz, a1, p->tw[1].p, Lx, m, lz, p1, p2, st);
+            pruned_xinv(Lx, p->tuning, a1, xs + off, ys + off, alpha, beta, p->tw[0].p, lines, Lx, p1, n, st);
+            LSFC_HIP(hipEventRecord(ev, st));
+            LSFC_HIP(hipStreamWaitEvent(hp->down, ev, 0));
+            LSFC_HIP(hipMemcpyAsync(yj + off, ys + off, (size_t)chunk * sizeof(cplx), hipMemcpyDeviceToHost, hp->down));
+        }
+        LSFC_HIP(hipEventRecord(hp->ev_xfree[sl], st));
+        LSFC_HIP(hipEventRecord(hp->ev_yfree[sl], hp->down));
     }
     LSFC_HIP(hipStreamSynchronize(hp->down));
     LSFC_HIP(hipStreamSynchronize(st));
@@ -578,11 +596,12 @@ static void convolve_any(lsfc_plan* p, const double* x, double* y, int64_t nrhs,
     }
     LSFC_REQUIRE(memspace == LSFC_MEM_HOST, "unknown memspace %d", memspace);
     const int group = (int)std::min<int64_t>(LSFC_MAX_BATCH, nrhs);
-    ensure_staging(p, p->N * group);
-    // large 3D vectors: the chunked pipeline above, one right-hand side after the other
+    // large 3D vectors: the chunked pipeline above (two staging slots, allocated there)
     const int K = host_pipeline_chunks(p);
+    if (K <= 1) ensure_staging(p, p->N * group);
     if (K > 1) {
-        for (int64_t j = 0; j < nrhs; ++j) host_pipelined_convolve(p, (const cplx*)x + j * p->N, (cplx*)y + j * p->N, use_nu, alpha, beta, K);
+        // (y aliasing x: right-hand side j + 1 is uploaded while j is downloaded into the same memory -- distinct vectors, no hazard)
+        host_pipelined_convolve(p, (const cplx*)x, (cplx*)y, nrhs, use_nu, alpha, beta, K);
         return;
     }
     // LSFC_HOST_COPY=sync (developer switch, diagnostics of the round-2 first-apply fault): the round-2 workaround, a

@@ -50,6 +50,8 @@ struct HostPipe {
     hipStream_t up = nullptr, down = nullptr;      // non-blocking: ordered against the plan's stream by the events only
     std::vector<hipEvent_t> ev_up, ev_down;        // chunk c of x has landed / chunk c of y is ready
     hipEvent_t ev_free = nullptr;                  // everything earlier on the plan's stream has finished with the staging buffers
+    hipEvent_t ev_xfree[2] = { nullptr, nullptr }; // staging slot s: its inverse x pass has read xs / its downloads have read ys
+    hipEvent_t ev_yfree[2] = { nullptr, nullptr };
     ~HostPipe();
 };
 

@@ -487,6 +487,17 @@ def test_host_vector_pipeline(lsfc, K, monkeypatch):
         lsfc.host_unregister(bp); lsfc.host_unregister(yp)
     assert np.array_equal(yp, y)
     assert rel_err(lsfc.FFTconvolution(M, b), o.convolve_reduced(G2, b, (n, m, l))) < TOL
+    # several right-hand sides: two staging slots, the download of one overlapping the upload of the next
+    B = np.stack([b, 1j * b[::-1], b.conj(), 0.5 * b, b[::-1]])
+    Y = lsfc.apply_batch(M, B, 0)
+    for r in range(B.shape[0]):
+        assert np.array_equal(Y[r], M * B[r]), r
+    Bp = B.copy()
+    lsfc.host_register(Bp)
+    try:
+        assert np.array_equal(lsfc.apply_batch(M, Bp, 0), Y)
+    finally:
+        lsfc.host_unregister(Bp)
 
 
 def test_first_apply_of_a_fresh_process(lsfc):
