@@ -403,30 +403,52 @@ template <int BIT> __device__ __forceinline__ void xlane_step(cplx& a, cplx& b) 
     b = make_double2(__hiloint2double((int)b1, (int)b0), __hiloint2double((int)b3, (int)b2));
 }
 #endif
-// the exchange between the last two stages of C can run through the lanes of layout LL
-template <class C, class LL> constexpr bool xlane_ok() {
-    if constexpr (C::NS != 3) return false;
-    else return C::R1 == 8 && C::R2 == 8 && C::template LS<2>() == 8 && C::T % 8 == 0 && C::E % 8 == 0 && (LL::LSTR == 8 || LL::LSTR == 4) && !LL::SPLIT;
+// Which exchanges can run through the lanes.  For ANY two consecutive stages S, S + 1 of equal radix R the exchange is, for every u,
+// an R x R transpose between the slot index q and log2(R) bits of the thread index: with b = t + T u = M_S beta + M' gamma + delta
+// (M' = M_S / R the butterfly stride of stage S + 1, gamma < R, delta < M')
+//     stage_pos<C, S>(t, u + NB q) = LS_S beta + M' gamma + delta + M_S q  ==  stage_pos<C, S + 1>(t', u + NB q')
+//     with b' = M_S beta + M' q + delta and q' = gamma:   slot (u, q) of thread t  <->  slot (u, gamma(t)) of thread t[gamma := q]
+// and when M_S divides T the bits of gamma are bits log2(M') .. log2(M_S) - 1 of t itself (checked for every factorisation by
+// tests/emu).  Lane = line + LSTR * t, so they sit at lane bits LB = log2(LSTR) + log2(M') and up: usable when they are bits 2..5.
+// 16.8.8 / 24.8.8 / 8.8.8: the exchange 1 -> 2 (t bits 0..2); 20.4.4.4 in 4-line workgroups: 1 -> 2 (t bits 2, 3 = lane bits 4, 5:
+// two permlane swaps per dword pair) AND 2 -> 3 (t bits 0, 1 = lane bits 2, 3), which leaves ONE exchange through LDS per direction.
+constexpr int xlane_log2(int x) { int r = 0; while ((1 << r) < x) ++r; return r; }
+template <class C, int S> constexpr int xlane_mnext() { return C::template LS<S>() / C::template R<S>() / C::template R<S>(); }   // M'
+template <class C, int S, int LSTR> constexpr int xlane_lowbit() { return xlane_log2(LSTR) + xlane_log2(xlane_mnext<C, S>() > 0 ? xlane_mnext<C, S>() : 1); }
+template <class C, int S, class LL> constexpr bool xlane_stage_ok() {
+    if constexpr (S < 1 || S + 1 >= C::NS) return false;
+    else {
+        constexpr int R = C::template R<S>(), M = C::template LS<S>() / R;
+        if constexpr (R != C::template R<S + 1>() || (R != 4 && R != 8) || M % R != 0 || C::T % M != 0 || C::E % R != 0) return false;
+        else {
+            constexpr int MN = M / R, LB = xlane_lowbit<C, S, LL::LSTR>();
+            return (MN & (MN - 1)) == 0 && (LL::LSTR == 8 || LL::LSTR == 4) && !LL::SPLIT && LB >= 2 && LB + xlane_log2(R) <= 6;
+        }
+    }
 }
-// the three butterfly steps, written over a primitive STEP(bit, a, b) so that tests/emu can run the same schedule on an
-// emulated wavefront
-template <class C, int LSTR, class STEP> __device__ __forceinline__ void xlane_transpose8_with(cplx (&v)[C::E], STEP&& step) {
-    constexpr int NB = C::E / 8;
+// at least one exchange of C can run through the lanes of layout LL
+template <class C, class LL> constexpr bool xlane_ok() { return xlane_stage_ok<C, 1, LL>() || xlane_stage_ok<C, 2, LL>(); }
+// the butterfly steps of the transpose after stage S, written over a primitive STEP(k, a, b) (k-th of the log2(R) lane bits) so
+// that tests/emu can run the same schedule on an emulated wavefront
+template <class C, int S, class STEP> __device__ __forceinline__ void xlane_transpose_with(cplx (&v)[C::E], STEP&& step) {
+    constexpr int R = C::template R<S>(), NB = C::E / R, NK = xlane_log2(R);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < NK; ++k) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < R; ++q)
                 if (!((q >> k) & 1)) step(k, v[u + NB * q], v[u + NB * (q | (1 << k))]);
         }
     }
 }
 #ifndef LSFC_FFT_HOST_EMULATION
-template <class C, int LSTR> __device__ __forceinline__ void xlane_transpose8(cplx (&v)[C::E]) {
-    constexpr int LB = LSTR == 8 ? 3 : 2;
-    xlane_transpose8_with<C, LSTR>(v, [](int k, cplx& a, cplx& b) __attribute__((always_inline)) {
-        if (k == 0) xlane_step<LB>(a, b); else if (k == 1) xlane_step<LB + 1>(a, b); else xlane_step<LB + 2>(a, b);
+template <class C, int S, int LSTR> __device__ __forceinline__ void xlane_transpose(cplx (&v)[C::E]) {
+    constexpr int LB = xlane_lowbit<C, S, LSTR>(), NK = xlane_log2(C::template R<S>());
+    xlane_transpose_with<C, S>(v, [](int k, cplx& a, cplx& b) __attribute__((always_inline)) {
+        if (k == 0) xlane_step<LB>(a, b);
+        else if (k == 1) xlane_step<LB + 1>(a, b);
+        else { if constexpr (NK > 2) xlane_step<LB + 2>(a, b); }
     });
 }
 #endif
@@ -577,48 +599,45 @@ __device__ __forceinline__ void fft_inverse(cplx (&v)[C::E], int t, const cplx* 
 // DEFER: the barriers that free the exchange buffer are taken inside the following stage, before its first store (BARF), and
 // by the CALLER after the last forward stage (before it stores into the buffer) and before the first stage of the next
 // forward transform (a stage with BARF, or a barrier).
-// XL: the exchange between the last two (radix-8) stages runs through the lanes (xlane_transpose8), not LDS.
+// XL: every exchange S -> S + 1, S >= 1, that can (xlane_stage_ok) runs through the lanes (xlane_transpose), not LDS.
+template <class C, class LL, int S, bool TWFULL, bool DEFER, bool XL>
+__device__ __forceinline__ void fft_forward_ws_from(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
+    if constexpr (S == C::NS - 1) stage<C, S, +1, 0, TWFULL>(v, t, tw);
+    else if constexpr (XL && xlane_stage_ok<C, S, LL>()) {
+        stage<C, S, +1, 0, TWFULL>(v, t, tw);
+        xlane_transpose<C, S, LL::LSTR>(v);
+        fft_forward_ws_from<C, LL, S + 1, TWFULL, DEFER, XL>(v, t, tw, smem, off, xi);
+    } else {
+        stage<C, S, +1, 0, TWFULL, false, LL, DEFER>(v, t, tw, smem, off, xi);
+        exchange_read<C, S + 1, LL, !DEFER>(v, t, smem, off, xi);
+        fft_forward_ws_from<C, LL, S + 1, TWFULL, DEFER, XL>(v, t, tw, smem, off, xi);
+    }
+}
 template <class C, class LL, bool PRUNE_IN, bool TWFULL, bool DEFER = false, bool XL = false, class F>
 __device__ __forceinline__ void fft_forward_ws(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi, F&& hook) {
     static_assert(!XL || (xlane_ok<C, LL>() && !DEFER), "fft_forward_ws: lane exchange not available for this line / layout");
     stage<C, 0, +1, PRUNE_IN ? 1 : 0, TWFULL, false, LL, DEFER>(v, t, tw, smem, off, xi);
     hook();
     exchange_read<C, 1, LL, !DEFER>(v, t, smem, off, xi);
-    if constexpr (C::NS == 2) stage<C, 1, +1, 0, TWFULL>(v, t, tw);
-    else if constexpr (XL) {
-        stage<C, 1, +1, 0, TWFULL>(v, t, tw);
-        xlane_transpose8<C, LL::LSTR>(v);
-        stage<C, 2, +1, 0, TWFULL>(v, t, tw);
+    fft_forward_ws_from<C, LL, 1, TWFULL, DEFER, XL>(v, t, tw, smem, off, xi);
+}
+// stage S (>= 1) backwards and the exchange S -> S - 1 behind it, down to the slots of stage 0
+template <class C, class LL, int S, bool TWFULL, bool DEFER, bool XL>
+__device__ __forceinline__ void fft_inverse_ws_from(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
+    if constexpr (XL && xlane_stage_ok<C, S - 1, LL>()) {
+        stage<C, S, -1, 0, TWFULL>(v, t, tw);
+        xlane_transpose<C, S - 1, LL::LSTR>(v);
     } else {
-        stage<C, 1, +1, 0, TWFULL, false, LL, DEFER>(v, t, tw, smem, off, xi);
-        exchange_read<C, 2, LL, !DEFER>(v, t, smem, off, xi);
-        if constexpr (C::NS == 3) stage<C, 2, +1, 0, TWFULL>(v, t, tw);
-        else {
-            stage<C, 2, +1, 0, TWFULL, false, LL, DEFER>(v, t, tw, smem, off, xi);
-            exchange_read<C, 3, LL, !DEFER>(v, t, smem, off, xi);
-            stage<C, 3, +1, 0, TWFULL>(v, t, tw);
-        }
+        // (the caller has synchronised after its own use of the buffer: the first storing stage stores at once)
+        stage<C, S, -1, 0, TWFULL, false, LL, (DEFER && S < C::NS - 1)>(v, t, tw, smem, off, xi);
+        exchange_read<C, S - 1, LL, !DEFER>(v, t, smem, off, xi);
     }
+    if constexpr (S > 1) fft_inverse_ws_from<C, LL, S - 1, TWFULL, DEFER, XL>(v, t, tw, smem, off, xi);
 }
 template <class C, class LL, bool PRUNE_OUT, bool TWFULL, bool DEFER = false, bool XL = false>
 __device__ __forceinline__ void fft_inverse_ws(cplx (&v)[C::E], int t, const cplx* __restrict__ tw, char* smem, int off, int xi) {
     static_assert(!XL || (xlane_ok<C, LL>() && !DEFER), "fft_inverse_ws: lane exchange not available for this line / layout");
-    // (the caller has synchronised after its own use of the buffer: the first stage stores at once)
-    if constexpr (XL) {
-        stage<C, 2, -1, 0, TWFULL>(v, t, tw);
-        xlane_transpose8<C, LL::LSTR>(v);
-    } else {
-    if constexpr (C::NS >= 4) {
-        stage<C, 3, -1, 0, TWFULL, false, LL>(v, t, tw, smem, off, xi);
-        exchange_read<C, 2, LL, !DEFER>(v, t, smem, off, xi);
-    }
-    if constexpr (C::NS >= 3) {
-        stage<C, 2, -1, 0, TWFULL, false, LL, (DEFER && C::NS >= 4)>(v, t, tw, smem, off, xi);
-        exchange_read<C, 1, LL, !DEFER>(v, t, smem, off, xi);
-    }
-    }
-    stage<C, 1, -1, 0, TWFULL, false, LL, (DEFER && C::NS >= 3)>(v, t, tw, smem, off, xi);
-    exchange_read<C, 0, LL, !DEFER>(v, t, smem, off, xi);
+    fft_inverse_ws_from<C, LL, C::NS - 1, TWFULL, DEFER, XL>(v, t, tw, smem, off, xi);
     stage<C, 0, -1, PRUNE_OUT ? 2 : 0, TWFULL>(v, t, tw);
 }
 #endif // !LSFC_FFT_HOST_EMULATION

@@ -128,18 +128,20 @@ static int check_model_steps() {
     }
     return bad;
 }
-// exchange 1 -> 2 (and back) of a line whose last two stages are radix 8, run wavefront by wavefront with the schedule the
-// device uses (xlane_transpose8_with); lane = line + LSTR * t
-template <class C, int LSTR>
+// the exchange S -> S + 1 (and back) of two stages of equal radix, run wavefront by wavefront with the schedule the device uses
+// (xlane_transpose_with); lane = line + LSTR * t, lane bits from xlane_lowbit
+template <class C, int S, int LSTR>
 static void emu_xlane(std::vector<std::vector<cplx>>& regs, int nlines) {
     static_assert(64 % LSTR == 0, "interleaved lines");
-    constexpr int LB = LSTR == 8 ? 3 : 2, TPW = 64 / LSTR;                         // threads t of a line per wavefront
+    constexpr int LB = xlane_lowbit<C, S, LSTR>(), TPW = (64 / LSTR < C::T) ? 64 / LSTR : C::T;   // threads t of a line per wavefront
+    constexpr int R = C::template R<S>(), NB = C::E / R, NK = xlane_log2(R);
+    static_assert(LB >= 2 && LB + NK <= 6, "lane bits 2..5");
     for (int t0 = 0; t0 < C::T; t0 += TPW) {
-        // gather the wavefront: lane l holds thread t0 + l / LSTR of line l % LSTR
+        // gather the wavefront: lane l holds thread t0 + l / LSTR of line l % LSTR (lanes beyond the line's threads: scratch)
+        std::vector<std::vector<cplx>> scratch(64, std::vector<cplx>(C::E));
         std::vector<cplx*> lane(64);
-        for (int l = 0; l < 64; ++l) lane[l] = regs[(l % LSTR) * C::T + t0 + l / LSTR].data();
-        constexpr int NB = C::E / 8;
-        for (int u = 0; u < NB; ++u) for (int k = 0; k < 3; ++k) for (int q = 0; q < 8; ++q) if (!((q >> k) & 1)) {
+        for (int l = 0; l < 64; ++l) lane[l] = (l / LSTR < TPW) ? regs[(l % LSTR) * C::T + t0 + l / LSTR].data() : scratch[l].data();
+        for (int u = 0; u < NB; ++u) for (int k = 0; k < NK; ++k) for (int q = 0; q < R; ++q) if (!((q >> k) & 1)) {
             const int ea = u + NB * q, eb = u + NB * (q | (1 << k));
             double ar[64], ai[64], br[64], bi[64];
             for (int l = 0; l < 64; ++l) { ar[l] = lane[l][ea].x; ai[l] = lane[l][ea].y; br[l] = lane[l][eb].x; bi[l] = lane[l][eb].y; }
@@ -150,13 +152,29 @@ static void emu_xlane(std::vector<std::vector<cplx>>& regs, int nlines) {
     (void)nlines;
 }
 // ... and the device's own schedule function must visit exactly those (k, slot pair)s in that order
-template <class C> static int check_xlane_schedule() {
-    constexpr int NB = C::E / 8;
+template <class C, int S> static int check_xlane_schedule() {
+    constexpr int R = C::template R<S>(), NB = C::E / R, NK = xlane_log2(R);
     std::vector<int> want, got;
-    for (int u = 0; u < NB; ++u) for (int k = 0; k < 3; ++k) for (int q = 0; q < 8; ++q) if (!((q >> k) & 1)) { want.push_back(k); want.push_back(u + NB * q); want.push_back(u + NB * (q | (1 << k))); }
+    for (int u = 0; u < NB; ++u) for (int k = 0; k < NK; ++k) for (int q = 0; q < R; ++q) if (!((q >> k) & 1)) { want.push_back(k); want.push_back(u + NB * q); want.push_back(u + NB * (q | (1 << k))); }
     cplx v[C::E];
-    xlane_transpose8_with<C, 8>(v, [&](int k, cplx& a, cplx& b) { got.push_back(k); got.push_back((int)(&a - v)); got.push_back((int)(&b - v)); });
+    xlane_transpose_with<C, S>(v, [&](int k, cplx& a, cplx& b) { got.push_back(k); got.push_back((int)(&a - v)); got.push_back((int)(&b - v)); });
     return want == got ? 0 : 1;
+}
+// the tail of the forward transform from stage S on / of the inverse from stage S down, as fft_core.hpp's fft_*_ws_from
+template <class C, class LL, int S> static void emu_forward_from(std::vector<std::vector<cplx>>& regs, std::vector<char>& smem, int nlines, const cplx* tw, bool xl) {
+    if constexpr (S == C::NS - 1) emu_stage<C, S, +1, 0>(regs, nlines, tw);
+    else {
+        bool lanes = false;
+        if constexpr (xlane_stage_ok<C, S, LL>()) { if (xl) { lanes = true; emu_stage<C, S, +1, 0>(regs, nlines, tw); emu_xlane<C, S, LL::LSTR>(regs, nlines); } }
+        if (!lanes) emu_stage_ws<C, LL, S, S + 1, +1, 0>(regs, smem, nlines, tw);
+        emu_forward_from<C, LL, S + 1>(regs, smem, nlines, tw, xl);
+    }
+}
+template <class C, class LL, int S> static void emu_inverse_from(std::vector<std::vector<cplx>>& regs, std::vector<char>& smem, int nlines, const cplx* tw, bool xl) {
+    bool lanes = false;
+    if constexpr (xlane_stage_ok<C, S - 1, LL>()) { if (xl) { lanes = true; emu_stage<C, S, -1, 0>(regs, nlines, tw); emu_xlane<C, S - 1, LL::LSTR>(regs, nlines); } }
+    if (!lanes) emu_stage_ws<C, LL, S, S - 1, -1, 0>(regs, smem, nlines, tw);
+    if constexpr (S > 1) emu_inverse_from<C, LL, S - 1>(regs, smem, nlines, tw, xl);
 }
 static bool g_xlane = false;         // fourth sweep: the radix-8 <-> radix-8 exchange through the emulated lanes where the device can
 
@@ -175,21 +193,12 @@ template <class C, class LL> static double run_cfg(const char* name, bool prune)
     std::vector<char> smem(lds_elems * 16, 0);
     // forward
     constexpr bool WSOK = !LL::SPLIT;                                // stage-issued stores: whole-complex layouts
-    constexpr bool XLOK = xlane_ok<C, LL>();                         // lane exchange between the two radix-8 stages
+    constexpr bool XLOK = xlane_ok<C, LL>();                         // some exchange can run through the lanes
     const bool ws = g_ws && WSOK, xl = g_xlane && XLOK && nlines == LL::LSTR;
     if (ws) {
         if constexpr (WSOK) {
             if (prune) emu_stage_ws<C, LL, 0, 1, +1, 1>(regs, smem, nlines, tw.data()); else emu_stage_ws<C, LL, 0, 1, +1, 0>(regs, smem, nlines, tw.data());
-            if constexpr (C::NS == 2) emu_stage<C, 1, +1, 0>(regs, nlines, tw.data());
-            else if constexpr (C::NS == 3) {
-                if (xl) { if constexpr (XLOK) { emu_stage<C, 1, +1, 0>(regs, nlines, tw.data()); emu_xlane<C, LL::LSTR>(regs, nlines); } }
-                else emu_stage_ws<C, LL, 1, 2, +1, 0>(regs, smem, nlines, tw.data());
-                emu_stage<C, 2, +1, 0>(regs, nlines, tw.data());
-            } else {
-                emu_stage_ws<C, LL, 1, 2, +1, 0>(regs, smem, nlines, tw.data());
-                emu_stage_ws<C, LL, 2, 3, +1, 0>(regs, smem, nlines, tw.data());
-                emu_stage<C, 3, +1, 0>(regs, nlines, tw.data());
-            }
+            emu_forward_from<C, LL, 1>(regs, smem, nlines, tw.data(), xl);
         }
     } else {
     if (prune) emu_stage<C, 0, +1, 1>(regs, nlines, tw.data()); else emu_stage<C, 0, +1, 0>(regs, nlines, tw.data());
@@ -216,12 +225,7 @@ template <class C, class LL> static double run_cfg(const char* name, bool prune)
     // inverse
     if (ws) {
         if constexpr (WSOK) {
-            if constexpr (C::NS >= 4) emu_stage_ws<C, LL, 3, 2, -1, 0>(regs, smem, nlines, tw.data());
-            if constexpr (C::NS >= 3) {
-                if (xl) { if constexpr (XLOK) { emu_stage<C, 2, -1, 0>(regs, nlines, tw.data()); emu_xlane<C, LL::LSTR>(regs, nlines); } }
-                else emu_stage_ws<C, LL, 2, 1, -1, 0>(regs, smem, nlines, tw.data());
-            }
-            emu_stage_ws<C, LL, 1, 0, -1, 0>(regs, smem, nlines, tw.data());
+            emu_inverse_from<C, LL, C::NS - 1>(regs, smem, nlines, tw.data(), xl);
         }
     } else {
     if constexpr (C::NS >= 4) { emu_stage<C, 3, -1, 0>(regs, nlines, tw.data()); emu_exchange<C, LL, 3, 2>(regs, smem, nlines, 0); }
@@ -262,13 +266,16 @@ int main() {
     worst = fmax(worst, run_cfg<CFG, LdsLayout<8, -1, false>>(#CFG " whole tile swizzled", false)); } while (0)
     for (int pass = 0; pass < 3; ++pass) {
         g_twfull = pass >= 1; g_ws = pass >= 1; g_xlane = pass == 2;
-        printf("---- fused-pass forms: %s\n", pass == 0 ? "exchange()" : pass == 1 ? "stores from inside the stages, full table" : "+ lane exchange between the radix-8 stages");
+        printf("---- fused-pass forms: %s\n", pass == 0 ? "exchange()" : pass == 1 ? "stores from inside the stages, full table" : "+ lane exchanges between stages of equal radix");
         RUNZ(Cfg512); RUNZ(Cfg1024); RUNZ(Cfg1536); RUNZ(Cfg1280); RUNZ(Cfg2048); RUNZ(Cfg768); RUNZ(Cfg640);
+        if (pass == 2) { RUNZ(Cfg128); RUNZ(Cfg192); RUNZ(Cfg320); RUNZ(Cfg384); RUNZ(Cfg1024S); }
     }
     g_twfull = g_ws = g_xlane = false;
     static_assert(xlane_ok<Cfg1024, LdsLayout<8, 3, false>>() && xlane_ok<Cfg1536, LdsLayout<4, -1, false>>() && xlane_ok<Cfg512, LdsLayout<8, 3, false>>(), "lane exchange available");
-    static_assert(!xlane_ok<Cfg2048, LdsLayout<8, 3, false>>() && !xlane_ok<Cfg1280, LdsLayout<4, -1, false>>() && !xlane_ok<Cfg1024, LdsLayout<8, 3, true>>(), "lane exchange not available");
-    int bad = check_model_steps() + check_xlane_schedule<Cfg1024>() + check_xlane_schedule<Cfg1536>() + check_xlane_schedule<Cfg512>();
+    static_assert(!xlane_ok<Cfg2048, LdsLayout<8, 3, false>>() && !xlane_ok<Cfg768, LdsLayout<8, 3, false>>() && !xlane_ok<Cfg1024, LdsLayout<8, 3, true>>(), "lane exchange not available");
+    static_assert(xlane_stage_ok<Cfg1280, 1, LdsLayout<4, -1, false>>() && xlane_stage_ok<Cfg1280, 2, LdsLayout<4, -1, false>>() && !xlane_stage_ok<Cfg1280, 1, LdsLayout<8, 3, false>>() && xlane_stage_ok<Cfg1280, 2, LdsLayout<8, 3, false>>(), "20.4.4.4: both late exchanges in 4-line workgroups, the last one in 8-line workgroups");
+    static_assert(xlane_stage_ok<Cfg640, 1, LdsLayout<8, 3, false>>() && !xlane_stage_ok<Cfg640, 2, LdsLayout<8, 3, false>>() && xlane_stage_ok<Cfg320, 1, LdsLayout<8, 3, false>>() && xlane_stage_ok<Cfg384, 1, LdsLayout<8, 3, false>>(), "radix-4 pairs");
+    int bad = check_model_steps() + check_xlane_schedule<Cfg1024, 1>() + check_xlane_schedule<Cfg1536, 1>() + check_xlane_schedule<Cfg512, 1>() + check_xlane_schedule<Cfg1280, 1>() + check_xlane_schedule<Cfg1280, 2>();
     printf("lane-exchange primitive model / schedule mismatches: %d\n", bad);
     // ticket -> (tile, half) of the ticketed fused pass: every (tile, half) exactly once over the eight queues, pairs adjacent
     for (int half = 0; half < 2; ++half) for (unsigned ntiles = 16; ntiles <= 16 * 40; ntiles += 16) {

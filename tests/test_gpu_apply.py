@@ -265,7 +265,7 @@ def test_every_mixed_radix_line_length_on_every_axis_3d(lsfc, L, axis):
 
 
 @pytest.mark.parametrize("short", [0, 6])
-@pytest.mark.parametrize("L", [512, 1024, 1280, 1536, 2048])
+@pytest.mark.parametrize("L", [128, 192, 320, 384, 512, 640, 1024, 1280, 1536, 2048])
 def test_fused_pass_forms_even_symbol_long_z_lines(lsfc, L, short):
     # every form of the fused z pass on the long lines, against the oracle: one tile per workgroup (0), persistent whole
     # tiles (3), ticketed half tiles with per-XCD queues (5; the default at L = 1280 and 1536), ticketed whole tiles (6; the default at 1024).  They need the z-even half symbol,
@@ -283,8 +283,8 @@ def test_fused_pass_forms_even_symbol_long_z_lines(lsfc, L, short):
     want = o.apply_reduced(G2, nu, 2.0, b, (n, m, l))
     got = {}
     for form in (0, 3, 5, 6):
-        # xlane: the exchange between the two radix-8 stages of the 1024- and 1536-point lines through the lanes of the
-        # wavefront (forms 5 and 6) or through LDS
+        # xlane: the exchanges between stages of equal radix (8.8 of the 512-, 1024- and 1536-point lines, 4.4 of 128, 192, 320,
+        # 384, 640, and both 4.4 of 1280 = 20.4.4.4 in its half-tile form) through the lanes of the wavefront or through LDS
         for xl in (5, 3, 1, 0):
             M.set_tuning(z_persist=form, xlane=xl)
             got[form] = M * b
