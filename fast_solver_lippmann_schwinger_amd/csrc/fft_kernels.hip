@@ -367,9 +367,14 @@ template <class P> __device__ __forceinline__ P launder_s(P x) { asm volatile(""
 // tile of the mirror row, which reads the same symbol rows -- go to the next workgroups of that XCD that become free.  A workgroup whose queue is exhausted moves on to the next queue (xcd + 1, ...), so every ticket of
 // every queue is drawn whatever the placement of the workgroups (and the tail balances itself); it ends when all eight
 // are exhausted.  There is no waiting on other workgroups anywhere.
-template <class C, int LINES, bool SPLIT, bool TWL, bool HALF> constexpr size_t persist_lds_bytes() {
+// the exchange buffer, which between the transforms also stages the symbol's (L / 2 + 1) x LINES whole-complex mirror values
+template <class C, int LINES, bool SPLIT, bool HALF> constexpr size_t persist_xbuf_bytes() {
     using LL = LdsLayout<LINES, HALF ? -1 : 3, SPLIT>;
-    return (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes() + (TWL ? (size_t)C::TWLEN * sizeof(cplx) : 0);
+    constexpr size_t ex = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes(), stg = (size_t)(C::L / 2 + 1) * LINES * sizeof(cplx);
+    return ex > stg ? ex : stg;
+}
+template <class C, int LINES, bool SPLIT, bool TWL, bool HALF> constexpr size_t persist_lds_bytes() {
+    return persist_xbuf_bytes<C, LINES, SPLIT, HALF>() + (TWL ? (size_t)C::TWLEN * sizeof(cplx) : 0);
 }
 // TICKETS without HALF: whole tiles handed out the same way, in pairs (row, mirror row) per XCD queue.
 // XL (round 3) is a set of bits, chosen by the run-time knob "xlane" (0, 1, 3, 5; -1 = 5 where available, else 1):
@@ -431,7 +436,7 @@ void k_zfused_persist(cplx* __restrict__ data, const cplx* __restrict__ sym, con
         if (cur == DONE) return;
     } else if (cur >= nwork) return;                    // (uniform per workgroup; no inter-workgroup synchronisation anywhere)
     if constexpr (TWL) {
-        cplx* tl = reinterpret_cast<cplx*>(smem + (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes());
+        cplx* tl = reinterpret_cast<cplx*>(smem + persist_xbuf_bytes<C, LINES, SPLIT, HALF>());
         for (int i = threadIdx.x; i < C::TWLEN; i += C::T * LINES) tl[i] = tw[i];
         __syncthreads();
         tw = tl;
@@ -701,7 +706,7 @@ template <class C, bool SPLIT, bool LATE_SYM = false, bool TICKETS = false> stat
                                                             const int2* ytab, const int* zm, int nin, hipStream_t st, int xl = 0) {
     constexpr int LINES = XB;
     using LL = LdsLayout<LINES, 3, SPLIT>;
-    size_t lds = (size_t)LL::line_elems(C::L) * LINES * LL::elem_bytes();
+    size_t lds = persist_xbuf_bytes<C, LINES, SPLIT, false>();
     if (twl && lds + (size_t)C::TWLEN * sizeof(cplx) > (size_t)160 * 1024) twl = nullptr;
     auto k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false, LATE_SYM, false, TICKETS> : k_zfused_persist<C, LINES, SPLIT, false, false, LATE_SYM, false, TICKETS>;
     if (twl) {
@@ -709,8 +714,8 @@ template <class C, bool SPLIT, bool LATE_SYM = false, bool TICKETS = false> stat
         lds += (size_t)C::TWLEN * sizeof(cplx);
         tw = twl;
     }
-    // lane exchange between the two radix-8 stages (whole tiles, symbol after the first stage: the 512^3 and 256^3 forms)
-    if constexpr (xlane_ok<C, LL>() && LATE_SYM) {
+    // lane exchanges between stages of equal radix (whole-complex whole tiles, symbol after the first stage: the 512^3 and 256^3 forms)
+    if constexpr (xlane_ok<C, LL>() && !SPLIT && LATE_SYM) {
         if (xl == 1) {
             if (twl) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, true, LATE_SYM, false, TICKETS, 1> : k_zfused_persist<C, LINES, SPLIT, false, true, LATE_SYM, false, TICKETS, 1>;
             else     k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, SPLIT, true, false, LATE_SYM, false, TICKETS, 1> : k_zfused_persist<C, LINES, SPLIT, false, false, LATE_SYM, false, TICKETS, 1>;
@@ -764,6 +769,10 @@ template <class C> static void zfused_persist_half_t(cplx* data, const cplx* sym
         if constexpr (xlane_ok<C, LdsLayout<LINES, -1, false>>()) {
             if (xl) k = (nin == C::L / 2) ? k_zfused_persist<C, LINES, false, true, true, true, true, true, 1> : k_zfused_persist<C, LINES, false, false, true, true, true, true, 1>;
         }
+        // (tried in round 3: the ONE LDS exchange left per direction run split -- real parts, then imaginary parts, through half the
+        // buffer -- so that TWO half-tile workgroups fit a CU at 1280 / 1536 points: without the in-stage stores every output of the
+        // widest butterfly stays live next to the symbol values in flight, the kernels spill (240 / 472 bytes per lane), 640^3 ties
+        // at 30.4 ms and 768^3 loses 49.3 -> 60.7 ms; removed, profiles/r03_experiment_lane_exchange_radix4.log)
         LSFC_REQUIRE(twl != nullptr, "half-tile persistent pass: twiddle table missing");
         allow_lds(k, lds);
         const unsigned ntiles = (unsigned)((Lx / XB) * nouter);

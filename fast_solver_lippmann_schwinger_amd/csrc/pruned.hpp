@@ -25,8 +25,9 @@ struct PrunedTuning {
     int z_persist = -1;             // fused pass with a z-even symbol in the 3D layout: persistent software-pipelined kernel -- 1 whole-complex
                                     // exchanges, 2 split exchanges, 3 (auto) / 4 the same with the symbol loaded after the first forward
                                     // stage; 0 the one-tile-per-workgroup kernels
-    int xlane = -1;                 // fused pass, lines whose last two stages are radix 8 (512, 1024, 1536 points): the exchange between
-                                    // them through the lanes of the wavefront instead of LDS (1 / -1 auto: on; 0: LDS)
+    int xlane = -1;                 // fused pass, lines with two consecutive stages of equal radix (8.8: 512, 1024, 1536 points; 4.4: 128, 192,
+                                    // 320, 384, 640, 1280): the exchange between them through the lanes of the wavefront instead of LDS
+                                    // (1 / -1 auto: on; 0: LDS)
     int ytile_g = 0, ytile_z = 0;   // y passes: block-order tile (x'-groups x z planes); 0 = auto
     int batch_fuse = -1;            // several right-hand sides: 1 one fused pass per group, 0 member by member, -1 auto (fused while
                                     // the padded grid has <= 2^24 points, where launches and not bytes bound the apply:

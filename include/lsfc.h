@@ -244,8 +244,8 @@ int lsfc_profile_apply(lsfc_plan* plan, const double* x_dev, double* y_dev, int 
  * switches of DESIGN.md section 3: "split_x", "split_s" (re/im-split LDS exchanges of the x / y passes), "split_z",
  * "sym_prefetch", "tw_lds", "z_half" (fused pass: split exchanges, symbol prefetch, LDS-resident stage twiddles,
  * half-tile form), "z_persist" (fused pass: 0 one tile per workgroup, 1-4 persistent pipelined whole tiles (6: handed out by per-XCD tickets), 5 ticketed
- * half tiles, -1 by line length), "xlane" (fused pass, 512- / 1024- / 1536-point lines: the exchange between the two radix-8 stages through LDS, 0, or
- * through the lanes of the wavefront, 1; 5 = 1 + row pairs as work items, the default where available; 3 = 1 + mirror symbol values from L2), "ytile_g", "ytile_z" (block-order tile of the y passes), "batch_fuse"
+ * half tiles, -1 by line length), "xlane" (fused pass, lines with two consecutive stages of equal radix -- 8.8: 512, 1024, 1536 points; 4.4: 128, 192, 320, 384, 640, 1280 --
+ * the exchange between them through LDS, 0, or through the lanes of the wavefront, 1; 5 = 1 + row pairs as work items, the default where available; 3 = 1 + mirror symbol values from L2), "ytile_g", "ytile_z" (block-order tile of the y passes), "batch_fuse"
  * (lsfc_apply_batch: 1 one fused pass per group of right-hand sides, 0 member by member, -1 by grid size).  Any other
  * key is LSFC_EINVAL.  Results never depend on them beyond rounding (the forms differ in how twiddles are obtained). */
 int lsfc_plan_set_tuning(lsfc_plan* plan, const char* key, int value);
