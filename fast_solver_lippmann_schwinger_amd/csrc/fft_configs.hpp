@@ -18,7 +18,11 @@ using Cfg48   = Cfg<48,    4, 12, 4>;
 using Cfg96   = Cfg<96,    8, 12, 4, 2>;
 using Cfg192  = Cfg<192,  16, 12, 4, 4>;
 using Cfg384  = Cfg<384,  16, 24, 4, 4>;
-using Cfg768  = Cfg<768,  32, 24, 8, 4>;
+// 768 points: 12 elements per thread in four stages (round 3; before: 24.8.4 on 32 threads).  Twice the threads per line put two
+// waves on every SIMD instead of one, and the last exchange (4.4) runs through the lanes: 384^3 apply 5.90 -> 5.50 ms (fused pass
+// 2.62 -> 2.34, yfwd 1.08 -> 0.93).  The same step on the 384-point line (12.4.4.2 on 32 threads) is a tie (192^3 0.74 ms
+// either way) and was not taken (profiles/r03_experiment_lane_exchange_radix4.log)
+using Cfg768  = Cfg<768,  64, 12, 4, 4, 4>;
 using Cfg1536 = Cfg<1536, 64, 24, 8, 8>;
 // lines with one factor 5 (L = 5 * 2^k): first radix 20, 20 elements per thread
 using Cfg80   = Cfg<80,    4, 20, 4>;
