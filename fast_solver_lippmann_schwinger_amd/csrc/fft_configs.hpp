@@ -11,7 +11,9 @@ using Cfg512  = Cfg<512, 64,  8,  8, 8>;
 using Cfg1024 = Cfg<1024, 64, 16, 8, 8>;
 using Cfg2048 = Cfg<2048, 128, 16, 16, 8>;
 // four-stage, 8 elements per thread: half the registers of Cfg1024 for one more LDS exchange.  Measured slower on
-// MI355X (profiles/r01_experiment_e8_four_stage.log); kept as the tested instance of the 4-stage machinery.
+// MI355X (profiles/r01_experiment_e8_four_stage.log; again in round 3 with the persistent fused pass and its 4.4 exchange through
+// the lanes: fused pass 5.0 against 4.63 ms at 512^3, x and y passes equal, profiles/r03_experiment_lane_exchange_radix4.log);
+// kept as the tested instance of the 4-stage machinery.
 using Cfg1024S = Cfg<1024, 128, 8, 8, 4, 4>;
 // lines with one factor 3 (L = 3 * 2^k): the radix carrying it is the first one, 12 or 24 elements per thread
 using Cfg48   = Cfg<48,    4, 12, 4>;
