@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblsfc.so")
+# (developer override for A/B builds: LSFC_LIBRARY=/path/to/another/liblsfc.so; a missing file is an error either way)
+LIB_PATH = os.environ.get("LSFC_LIBRARY") or os.path.join(_HERE, "liblsfc.so")
 
 LSFC_QUAD_TRAPEZOIDAL, LSFC_QUAD_GREENGARD_VICO = 0, 1
 LSFC_MEM_HOST, LSFC_MEM_DEVICE = 0, 1

@@ -26,10 +26,13 @@ using Cfg384  = Cfg<384,  16, 24, 4, 4>;
 // either way) and was not taken (profiles/r03_experiment_lane_exchange_radix4.log)
 using Cfg768  = Cfg<768,  64, 12, 4, 4, 4>;
 using Cfg1536 = Cfg<1536, 64, 24, 8, 8>;
-// lines with one factor 5 (L = 5 * 2^k): first radix 20, 20 elements per thread
+// lines with one factor 5 (L = 5 * 2^k): first radix 20 (10 at 640 points), 20 elements per thread
 using Cfg80   = Cfg<80,    4, 20, 4>;
 using Cfg160  = Cfg<160,   8, 20, 4, 2>;
 using Cfg320  = Cfg<320,  16, 20, 4, 4>;
-using Cfg640  = Cfg<640,  32, 20, 4, 4, 2>;
+// 640 points: first radix 10 (two half-size butterflies per thread) and three radix-4 stages instead of 20.4.4.2 (round 3, same-box A/B of
+// two builds: 320^3 apply 3.52 -> 3.38 ms, yfwd 0.60 -> 0.555, fused pass 1.65 -> 1.57); the same change is a loss on the 320-point line
+// (10.4.4.2: 160^3 0.40 -> 0.46 ms) and a tie on the 160-point line, which stay (profiles/r03_experiment_lane_exchange_radix4.log)
+using Cfg640  = Cfg<640,  32, 10, 4, 4, 4>;
 using Cfg1280 = Cfg<1280, 64, 20, 4, 4, 4>;
 }} // namespace
