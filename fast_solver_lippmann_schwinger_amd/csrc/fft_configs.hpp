@@ -6,7 +6,7 @@ namespace lsfc { namespace fft {
 using Cfg32   = Cfg<32,   4,  8,  4>;
 using Cfg64   = Cfg<64,   8,  8,  8>;
 using Cfg128  = Cfg<128, 16,  8,  4, 4>;
-using Cfg256  = Cfg<256, 32,  8,  8, 4>;
+using Cfg256  = Cfg<256, 32,  4,  8, 8>;     // (round 3; 8.8.4 before: the 8.8 pair last lets the fused pass exchange through the lanes, 128^3 0.184 -> 0.178 ms)
 using Cfg512  = Cfg<512, 64,  8,  8, 8>;
 using Cfg1024 = Cfg<1024, 64, 16, 8, 8>;
 using Cfg2048 = Cfg<2048, 128, 16, 16, 8>;
@@ -25,7 +25,7 @@ using Cfg384  = Cfg<384,  16, 24, 4, 4>;
 // 2.62 -> 2.34, yfwd 1.08 -> 0.93).  The same step on the 384-point line (12.4.4.2 on 32 threads) is a tie (192^3 0.74 ms
 // either way) and was not taken (profiles/r03_experiment_lane_exchange_radix4.log)
 using Cfg768  = Cfg<768,  64, 12, 4, 4, 4>;
-using Cfg1536 = Cfg<1536, 64, 24, 8, 8>;
+using Cfg1536 = Cfg<1536, 64, 24, 8, 8>;     // (24.4.4.4 with two lane exchanges, as the 1280-point line: 768^3 49.4 -> 52.1 ms, not taken)
 // lines with one factor 5 (L = 5 * 2^k): first radix 20 (10 at 640 points), 20 elements per thread
 using Cfg80   = Cfg<80,    4, 20, 4>;
 using Cfg160  = Cfg<160,   8, 20, 4, 2>;

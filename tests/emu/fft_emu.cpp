@@ -272,7 +272,7 @@ int main() {
     }
     g_twfull = g_ws = g_xlane = false;
     static_assert(xlane_ok<Cfg1024, LdsLayout<8, 3, false>>() && xlane_ok<Cfg1536, LdsLayout<4, -1, false>>() && xlane_ok<Cfg512, LdsLayout<8, 3, false>>(), "lane exchange available");
-    static_assert(!xlane_ok<Cfg2048, LdsLayout<8, 3, false>>() && !xlane_ok<Cfg256, LdsLayout<8, 3, false>>() && !xlane_ok<Cfg1024, LdsLayout<8, 3, true>>(), "lane exchange not available");
+    static_assert(!xlane_ok<Cfg2048, LdsLayout<8, 3, false>>() && !xlane_ok<Cfg96, LdsLayout<8, 3, false>>() && !xlane_ok<Cfg1024, LdsLayout<8, 3, true>>(), "lane exchange not available");
     static_assert(xlane_stage_ok<Cfg1280, 1, LdsLayout<4, -1, false>>() && xlane_stage_ok<Cfg1280, 2, LdsLayout<4, -1, false>>() && !xlane_stage_ok<Cfg1280, 1, LdsLayout<8, 3, false>>() && xlane_stage_ok<Cfg1280, 2, LdsLayout<8, 3, false>>(), "20.4.4.4: both late exchanges in 4-line workgroups, the last one in 8-line workgroups");
     static_assert(!xlane_stage_ok<Cfg640, 1, LdsLayout<8, 3, false>>() && xlane_stage_ok<Cfg640, 2, LdsLayout<8, 3, false>>() && xlane_stage_ok<Cfg320, 1, LdsLayout<8, 3, false>>() && xlane_stage_ok<Cfg384, 1, LdsLayout<8, 3, false>>(), "radix-4 pairs");
     int bad = check_model_steps() + check_xlane_schedule<Cfg1024, 1>() + check_xlane_schedule<Cfg1536, 1>() + check_xlane_schedule<Cfg512, 1>() + check_xlane_schedule<Cfg1280, 1>() + check_xlane_schedule<Cfg1280, 2>();
