@@ -5,9 +5,9 @@ from .operators import (FastM, FastM3D, ConvergenceHistory, FFTconvolution, buil
                         buildFastConvolution3D, eltype, fastconvolution, gmres_, gmres_batch_, apply_batch, mul_, profile_apply,
                         referenceValsTrapRule, sampleG3D, sampleGConv, size, time_apply)
 from .preconditioner import SparsifyingPreconditioner
-from ._lib import LsfcError, device_count, load, host_register, host_unregister
+from ._lib import LsfcError, device_count, load, host_register, host_unregister, host_empty
 
 __all__ = ["FastM", "FastM3D", "ConvergenceHistory", "FFTconvolution", "buildFastConvolution",
            "buildFastConvolution3D", "eltype", "fastconvolution", "gmres_", "gmres_batch_", "apply_batch", "mul_", "profile_apply",
            "referenceValsTrapRule", "sampleG3D", "sampleGConv", "size", "time_apply", "LsfcError",
-           "device_count", "load", "SparsifyingPreconditioner", "host_register", "host_unregister"]
+           "device_count", "load", "SparsifyingPreconditioner", "host_register", "host_unregister", "host_empty"]

@@ -75,6 +75,8 @@ SIGNATURES = {
     "lsfc_memcpy_d2h": (_I, [_P, _P, C.c_size_t]),
     "lsfc_host_register": (_I, [_P, C.c_size_t]),
     "lsfc_host_unregister": (_I, [_P]),
+    "lsfc_host_alloc": (_I, [_PP, C.c_size_t]),
+    "lsfc_host_free": (_I, [_P]),
     "lsfc_dist_unique_id": (_I, [_P]),
     "lsfc_dist_plan_create_gv3d": (_I, [_PP, _L, _L, _L, _D, _D, _P, _U, _I, _I, _I, _P]),
     "lsfc_dist_sim_plan_create_gv3d": (_I, [_PP, _L, _L, _L, _D, _D, _P, _U, _I, _I, _I]),
@@ -124,6 +126,35 @@ def host_register(a):
 
 def host_unregister(a):
     check(load().lsfc_host_unregister(a.ctypes.data_as(C.c_void_p)))
+
+
+class _PinnedBlock:
+    """owner of one lsfc_host_alloc block; freed when the last numpy view of it is gone"""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        check(load().lsfc_host_alloc(C.byref(self.ptr), max(int(nbytes), 1)))
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().lsfc_host_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+def host_empty(shape, dtype="complex128"):
+    """numpy array in page-locked memory owned by the HIP runtime (lsfc_host_alloc): host-vector applies move it by DMA.
+    The preferred form of a page-locked work vector (page-aligned, shares no page with the process heap)."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    blk = _PinnedBlock(count * dt.itemsize)
+    buf = (C.c_char * max(blk.nbytes, 1)).from_address(blk.ptr.value)
+    buf._owner = blk                               # numpy keeps `buf` (its base) alive, `buf` keeps the block alive
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
 
 
 def device_count():

@@ -1076,5 +1076,9 @@ int lsfc_host_register(void* ptr, size_t bytes) {
     return guarded([&] { LSFC_REQUIRE(ptr && bytes, "NULL argument"); LSFC_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault)); });
 }
 int lsfc_host_unregister(void* ptr) { return guarded([&] { LSFC_REQUIRE(ptr, "NULL argument"); LSFC_HIP(hipHostUnregister(ptr)); }); }
+int lsfc_host_alloc(void** ptr, size_t bytes) {
+    return guarded([&] { LSFC_REQUIRE(ptr && bytes, "NULL argument"); *ptr = nullptr; LSFC_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault)); });
+}
+int lsfc_host_free(void* ptr) { return guarded([&] { if (ptr) LSFC_HIP(hipHostFree(ptr)); }); }
 
 } // extern "C"

@@ -262,6 +262,13 @@ int lsfc_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
  * Unregister before the memory is freed. */
 int lsfc_host_register(void* ptr, size_t bytes);
 int lsfc_host_unregister(void* ptr);
+/* Page-locked host memory OWNED BY THE RUNTIME (hipHostMalloc): the preferred way to get DMA-able work vectors -- page-aligned,
+ * shares no page with other allocations of the process and is not subject to the kernel's page migration, unlike a registered
+ * range of the caller's heap (lsfc_host_register pins user pages in place; ranges that share pages with other heap objects are
+ * best avoided, see DESIGN.md "host vectors").  A host that cannot adopt foreign memory for its vectors (Julia can:
+ * unsafe_wrap) keeps using pageable vectors or lsfc_host_register. */
+int lsfc_host_alloc(void** ptr, size_t bytes);
+int lsfc_host_free(void* ptr);
 
 /* ---- slab-distributed 3D operator (one process per GPU, RCCL over xGMI) ---- */
 

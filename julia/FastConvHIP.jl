@@ -108,6 +108,14 @@ end
 # page-lock long-lived work vectors of the solver (optional; ~4 ms per 512^3 apply): lsfc_host_register / lsfc_host_unregister
 host_register!(v::Vector{Complex{Float64}}) = (check(ccall((:lsfc_host_register, liblsfc), Cint, (Ptr{Cvoid}, Csize_t), v, sizeof(v))); v)
 host_unregister!(v::Vector{Complex{Float64}}) = (check(ccall((:lsfc_host_unregister, liblsfc), Cint, (Ptr{Cvoid},), v)); v)
+# ... or, preferred, work vectors in page-locked memory owned by the HIP runtime (lsfc_host_alloc): page-aligned, no page shared with the heap
+function host_vector(N::Integer)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:lsfc_host_alloc, liblsfc), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, N * sizeof(Complex{Float64})))
+    v = unsafe_wrap(Vector{Complex{Float64}}, Ptr{Complex{Float64}}(p[]), N; own = false)
+    finalizer(_ -> ccall((:lsfc_host_free, liblsfc), Cint, (Ptr{Cvoid},), p[]), v)
+    v
+end
 
 # FFTconvolution -- src/FastConvolution.jl:110-154 (nu only in the 2D trapezoidal branch), src/FastConvolution3D.jl:39-63
 function FFTconvolution(M::FastMHIP, b::Array{Complex{Float64},1})

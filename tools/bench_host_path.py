@@ -36,6 +36,15 @@ t = timed()
 print(json.dumps({"n": n, "vectors": "page-locked (lsfc_host_register)", "pipeline": tag, "ms_per_apply": round(1e3 * t, 2), "applies_per_s": round(1 / t, 2),
                   "same_result": bool(np.array_equal(ref, y))}), flush=True)
 lsfc.host_unregister(b); lsfc.host_unregister(y)
+bo, yo = lsfc.host_empty(b.shape), lsfc.host_empty(b.shape)       # page-locked memory owned by the runtime (lsfc_host_alloc)
+bo[:] = b; yo[:] = 0
+b_keep, y_keep = b, y
+b, y = bo, yo
+t = timed()
+print(json.dumps({"n": n, "vectors": "page-locked, runtime-owned (lsfc_host_alloc)", "pipeline": tag, "ms_per_apply": round(1e3 * t, 2), "applies_per_s": round(1 / t, 2),
+                  "same_result": bool(np.array_equal(ref, y))}), flush=True)
+b, y = b_keep, y_keep
+del bo, yo
 import torch
 xb = torch.from_numpy(b).cuda(); yb = torch.empty_like(xb)
 ms = lsfc.time_apply(M, xb, yb, 10) / 10
