@@ -29,6 +29,7 @@ DistState::~DistState() {
     for (hipEvent_t e : { ev_p1, ev_p1a, ev_backa }) if (e) (void)hipEventDestroy(e);
     if (cs1) (void)hipStreamDestroy(cs1);
     if (cs2) (void)hipStreamDestroy(cs2);
+    if (st2) (void)hipStreamDestroy(st2);
     if (comm2) (void)ncclCommDestroy((ncclComm_t)comm2);
     if (comm) (void)ncclCommDestroy((ncclComm_t)comm);
 }
@@ -137,9 +138,12 @@ void dist_convolve_dev(lsfc_plan* p, const cplx* x, cplx* y, bool use_nu, double
         LSFC_HIP(hipEventRecord(d->ev_in[c], d->cs1));
     }
     for (int c = 0; c < K; ++c) {
-        LSFC_HIP(hipStreamWaitEvent(st, d->ev_in[c], 0));
-        phase2(p, c, st);
-        LSFC_HIP(hipEventRecord(d->ev_done[c], st));
+        // (two compute streams: a chunk always runs on the stream of its parity, so its buffers -- A2 / R1 chunk c -- stay ordered
+        // from one apply to the next; everything the second stream does is behind ev_done -> cs2 -> ev_back -> the inverse x pass)
+        hipStream_t cst = ((c & 1) && d->st2) ? d->st2 : st;
+        LSFC_HIP(hipStreamWaitEvent(cst, d->ev_in[c], 0));
+        phase2(p, c, cst);
+        LSFC_HIP(hipEventRecord(d->ev_done[c], cst));
         LSFC_HIP(hipStreamWaitEvent(d->cs2, d->ev_done[c], 0));
         // (the S1 blocks this receive overwrites belong to chunk c, whose way-in sends finished before ev_in[c])
         if (edges && c == K - 1) {
@@ -244,6 +248,11 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     if (!sim && (nranks > 1 || d->force_overlap || member)) {
         LSFC_HIP(hipStreamCreateWithFlags(&d->cs1, hipStreamNonBlocking));
         LSFC_HIP(hipStreamCreateWithFlags(&d->cs2, hipStreamNonBlocking));
+        // two compute streams (default; LSFC_DIST_COMPUTE_STREAMS=1: one): with chunks of the size a rank of an 8-GPU job transforms
+        // (32 x' of 1024: 12 short launches per apply) the ramp of a chunk's kernels fills the tail of the previous chunk's --
+        // one rank, 32 such chunks at 512^3: 15.93 -> 15.25-15.5 ms; neutral with 4 or 8 large chunks (profiles/r03_dist_two_compute_streams.log)
+        const char* cse = getenv("LSFC_DIST_COMPUTE_STREAMS");
+        if (!member && K >= 2 && !(cse && atoi(cse) == 1)) LSFC_HIP(hipStreamCreateWithFlags(&d->st2, hipStreamNonBlocking));
         for (hipEvent_t* e : { &d->ev_p1, &d->ev_p1a, &d->ev_backa }) LSFC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         d->ev_in.resize((size_t)K); d->ev_done.resize((size_t)K); d->ev_back.resize((size_t)K);
         for (int c = 0; c < K; ++c) {

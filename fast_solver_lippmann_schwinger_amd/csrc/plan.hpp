@@ -71,6 +71,8 @@ struct DistState {
     DevBuf<cplx> S1;         // [nranks][K][Wc][m][lz]: xfwd output packed per (destination rank, chunk) / xinv input
     DevBuf<cplx> R1;         // [K][Wc][m][l]: per chunk the natural layout on its x' range (received blocks concatenated)
     hipStream_t cs1 = nullptr, cs2 = nullptr;      // communication streams (in / back)
+    hipStream_t st2 = nullptr;                     // second compute stream (LSFC_DIST_COMPUTE_STREAMS=2): odd chunks run on it, so that the
+                                                   // ramp of one chunk's kernels fills the tail of the previous chunk's
     std::vector<hipEvent_t> ev_in, ev_done, ev_back;
     hipEvent_t ev_p1 = nullptr, ev_p1a = nullptr, ev_backa = nullptr;   // x pass done / its first z half done / first z half of the last chunk back
     ~DistState();
