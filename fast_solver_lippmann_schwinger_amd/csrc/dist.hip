@@ -252,7 +252,7 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
         // (32 x' of 1024: 12 short launches per apply) the ramp of a chunk's kernels fills the tail of the previous chunk's --
         // one rank, 32 such chunks at 512^3: 15.93 -> 15.25-15.5 ms; neutral with 4 or 8 large chunks (profiles/r03_dist_two_compute_streams.log)
         const char* cse = getenv("LSFC_DIST_COMPUTE_STREAMS");
-        if (!member && K >= 2 && !(cse && atoi(cse) == 1)) LSFC_HIP(hipStreamCreateWithFlags(&d->st2, hipStreamNonBlocking));
+        if (K >= 2 && !(cse && atoi(cse) == 1)) LSFC_HIP(hipStreamCreateWithFlags(&d->st2, hipStreamNonBlocking));
         for (hipEvent_t* e : { &d->ev_p1, &d->ev_p1a, &d->ev_backa }) LSFC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         d->ev_in.resize((size_t)K); d->ev_done.resize((size_t)K); d->ev_back.resize((size_t)K);
         for (int c = 0; c < K; ++c) {
@@ -406,12 +406,13 @@ void multi_convolve_dev(lsfc_plan* root, const cplx* const* x, cplx* const* y, b
     for (int c = 0; c < K; ++c) {
         for (int r = 0; r < P; ++r) {
             M.dev(r);
-            M.wait_all(M.st(r), &DistState::ev_in, c);          // copy transport: every source signals its own blocks
-            phase2(M.sub(r), c, M.st(r));
-            LSFC_HIP(hipEventRecord(M.d(r)->ev_done[(size_t)c], M.st(r)));
+            hipStream_t cst = ((c & 1) && M.d(r)->st2) ? M.d(r)->st2 : M.st(r);   // odd chunks: the second compute stream (as dist_convolve_dev)
+            M.wait_all(cst, &DistState::ev_in, c);              // copy transport: every source signals its own blocks
+            phase2(M.sub(r), c, cst);
+            LSFC_HIP(hipEventRecord(M.d(r)->ev_done[(size_t)c], cst));
             LSFC_HIP(hipStreamWaitEvent(M.d(r)->cs2, M.d(r)->ev_done[(size_t)c], 0));
         }
-        if (!overlap) for (int r = 0; r < P; ++r) { M.dev(r); LSFC_HIP(hipStreamSynchronize(M.st(r))); }
+        if (!overlap) for (int r = 0; r < P; ++r) { M.dev(r); LSFC_HIP(hipStreamSynchronize(M.st(r))); if (M.d(r)->st2) LSFC_HIP(hipStreamSynchronize(M.d(r)->st2)); }
         if (edges && c == K - 1) {
             M.exchange(c, true, 0, 0);
             for (int r = 0; r < P; ++r) { M.dev(r); LSFC_HIP(hipEventRecord(M.d(r)->ev_backa, M.d(r)->cs2)); }
