@@ -9,7 +9,7 @@ using Cfg128  = Cfg<128, 16,  8,  4, 4>;
 using Cfg256  = Cfg<256, 32,  4,  8, 8>;     // (round 3; 8.8.4 before: the 8.8 pair last lets the fused pass exchange through the lanes, 128^3 0.184 -> 0.178 ms)
 using Cfg512  = Cfg<512, 64,  8,  8, 8>;
 using Cfg1024 = Cfg<1024, 64, 16, 8, 8>;
-using Cfg2048 = Cfg<2048, 128, 16, 16, 8>;
+using Cfg2048 = Cfg<2048, 128, 8, 16, 16>;   // (round 3; 16.16.8 before: the 16.16 pair last runs through the lanes in 4-line workgroups -- 2D n = 1024 58.2 -> 55.4 us, 1024^3 110 -> 107.5 ms)
 // four-stage, 8 elements per thread: half the registers of Cfg1024 for one more LDS exchange.  Measured slower on
 // MI355X (profiles/r01_experiment_e8_four_stage.log; again in round 3 with the persistent fused pass and its 4.4 exchange through
 // the lanes: fused pass 5.0 against 4.63 ms at 512^3, x and y passes equal, profiles/r03_experiment_lane_exchange_radix4.log);

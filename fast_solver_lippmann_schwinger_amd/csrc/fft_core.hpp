@@ -419,7 +419,7 @@ template <class C, int S, class LL> constexpr bool xlane_stage_ok() {
     if constexpr (S < 1 || S + 1 >= C::NS) return false;
     else {
         constexpr int R = C::template R<S>(), M = C::template LS<S>() / R;
-        if constexpr (R != C::template R<S + 1>() || (R != 4 && R != 8) || M % R != 0 || C::T % M != 0 || C::E % R != 0) return false;
+        if constexpr (R != C::template R<S + 1>() || (R != 4 && R != 8 && R != 16) || M % R != 0 || C::T % M != 0 || C::E % R != 0) return false;
         else {
             constexpr int MN = M / R, LB = xlane_lowbit<C, S, LL::LSTR>();
             return (MN & (MN - 1)) == 0 && (LL::LSTR == 8 || LL::LSTR == 4) && !LL::SPLIT && LB >= 2 && LB + xlane_log2(R) <= 6;
@@ -448,7 +448,8 @@ template <class C, int S, int LSTR> __device__ __forceinline__ void xlane_transp
     xlane_transpose_with<C, S>(v, [](int k, cplx& a, cplx& b) __attribute__((always_inline)) {
         if (k == 0) xlane_step<LB>(a, b);
         else if (k == 1) xlane_step<LB + 1>(a, b);
-        else { if constexpr (NK > 2) xlane_step<LB + 2>(a, b); }
+        else if (k == 2) { if constexpr (NK > 2) xlane_step<LB + 2>(a, b); }
+        else { if constexpr (NK > 3) xlane_step<LB + 3>(a, b); }
     });
 }
 #endif

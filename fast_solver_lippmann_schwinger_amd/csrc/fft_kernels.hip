@@ -233,12 +233,20 @@ void k_zfused(cplx* __restrict__ data, const cplx* __restrict__ sym, const cplx*
         tw = tl;
     }
     // (whole-complex layouts: exchange stores issued from inside the stages, fft_core.hpp)
+    // ... and the exchanges between stages of equal radix through the lanes of the wavefront where the line and the layout allow it
+    // (fft_core.hpp xlane_stage_ok; whole wavefronts only): one LDS round trip and two workgroup barriers less per direction in a
+    // kernel that is a chain of latencies on the small grids and in 2D
+#ifdef LSFC_NO_XLANE_ONE_TILE
+    constexpr bool XL1 = false;
+#else
+    constexpr bool XL1 = !SPLIT && xlane_ok<C, LL>() && (C::T * LINES) % 64 == 0;
+#endif
     auto fwd = [&](cplx (&w)[E]) {
-        if constexpr (!SPLIT) fft_forward_ws<C, LL, true, TWL>(w, t, tw, smem, 0, li, [] {});
+        if constexpr (!SPLIT) fft_forward_ws<C, LL, true, TWL, false, XL1>(w, t, tw, smem, 0, li, [] {});
         else fft_forward<C, LL, true, TWL>(w, t, tw, smem, 0, li);
     };
     auto inv = [&](cplx (&w)[E]) {
-        if constexpr (!SPLIT) fft_inverse_ws<C, LL, true, TWL>(w, t, tw, smem, 0, li);
+        if constexpr (!SPLIT) fft_inverse_ws<C, LL, true, TWL, false, XL1>(w, t, tw, smem, 0, li);
         else fft_inverse<C, LL, true, TWL>(w, t, tw, smem, 0, li);
     };
     cplx v[E];

@@ -263,6 +263,7 @@ int main() {
 #define RUNZ(CFG) do { \
     worst = fmax(worst, run_cfg<CFG, LdsLayout<4, -1, false>>(#CFG " half-tile swizzled", true)); \
     worst = fmax(worst, run_cfg<CFG, LdsLayout<8, 3, false>>(#CFG " whole tile", true)); \
+    worst = fmax(worst, run_cfg<CFG, LdsLayout<4, 3, false>>(#CFG " half tile, padded (one-tile kernels)", true)); \
     worst = fmax(worst, run_cfg<CFG, LdsLayout<8, -1, false>>(#CFG " whole tile swizzled", false)); } while (0)
     for (int pass = 0; pass < 3; ++pass) {
         g_twfull = pass >= 1; g_ws = pass >= 1; g_xlane = pass == 2;
