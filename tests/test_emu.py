@@ -14,7 +14,7 @@ def test_fft_line_transform_emulation(tmp_path):
     exe = str(tmp_path / "fft_emu")
     # AddressSanitizer + UBSan on the CPU build: the index algebra of every layout (padded, XOR-swizzled), the in-stage exchange
     # stores and the lane-exchange schedule run under them
-    r = subprocess.run(["g++", "-std=c++17", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+    r = subprocess.run(["g++", "-std=c++17", "-O0", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
                         os.path.join(ROOT, "tests", "emu", "fft_emu.cpp")], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
     r = subprocess.run([exe], capture_output=True, timeout=600)
