@@ -248,11 +248,14 @@ static void create_dist_plan(lsfc_plan** out, int64_t n, int64_t m, int64_t l, d
     if (!sim && (nranks > 1 || d->force_overlap || member)) {
         LSFC_HIP(hipStreamCreateWithFlags(&d->cs1, hipStreamNonBlocking));
         LSFC_HIP(hipStreamCreateWithFlags(&d->cs2, hipStreamNonBlocking));
-        // two compute streams (default; LSFC_DIST_COMPUTE_STREAMS=1: one): with chunks of the size a rank of an 8-GPU job transforms
-        // (32 x' of 1024: 12 short launches per apply) the ramp of a chunk's kernels fills the tail of the previous chunk's --
-        // one rank, 32 such chunks at 512^3: 15.93 -> 15.25-15.5 ms; neutral with 4 or 8 large chunks (profiles/r03_dist_two_compute_streams.log)
+        // LSFC_DIST_COMPUTE_STREAMS=2 (opt-in): odd chunks on a second compute stream.  With chunks of the size a rank of an 8-GPU job
+        // transforms (32 x' of 1024: 12 short launches per apply) the ramp of a chunk's kernels fills the tail of the previous chunk's --
+        // one rank, 32 such chunks at 512^3: 15.93 -> 15.25-15.5 ms; neutral with 4 or 8 large chunks (profiles/r03_dist_two_compute_streams.log).
+        // Not the default: that was measured with device-to-device copies as the exchange; RCCL's transfer kernels need CUs, which
+        // they get at the boundaries between compute kernels -- two compute streams close those gaps, and no multi-GPU node has
+        // been available to see what that does to the exchange.
         const char* cse = getenv("LSFC_DIST_COMPUTE_STREAMS");
-        if (K >= 2 && !(cse && atoi(cse) == 1)) LSFC_HIP(hipStreamCreateWithFlags(&d->st2, hipStreamNonBlocking));
+        if (K >= 2 && cse && atoi(cse) == 2) LSFC_HIP(hipStreamCreateWithFlags(&d->st2, hipStreamNonBlocking));
         for (hipEvent_t* e : { &d->ev_p1, &d->ev_p1a, &d->ev_backa }) LSFC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         d->ev_in.resize((size_t)K); d->ev_done.resize((size_t)K); d->ev_back.resize((size_t)K);
         for (int c = 0; c < K; ++c) {

@@ -55,6 +55,7 @@ def test_three_stream_pipeline_event_logic_single_rank(lsfc, monkeypatch, split_
     ref = Mseq * b
     monkeypatch.setenv("LSFC_DIST_FORCE_OVERLAP", "1")
     monkeypatch.setenv("LSFC_DIST_SPLIT_EDGES", split_edges)   # z-half split of the first exchange in / last exchange back
+    monkeypatch.setenv("LSFC_DIST_COMPUTE_STREAMS", "2" if split_edges == "1" else "1")   # odd chunks on a second compute stream (opt-in form)
     Mov = build_distributed_3d(n, h, 12.0, nu, 0, 1, 0)
     xb = torch.from_numpy(b).cuda()
     yb = torch.empty_like(xb)
@@ -117,6 +118,8 @@ def test_simulated_ranks_grid_sizes_not_powers_of_two(lsfc, shape, ranks):
 @pytest.mark.parametrize("ndev,overlap", [(1, "1"), (2, "1"), (4, "1"), (4, "0"), (8, "1")])
 def test_multi_device_plan_matches_oracle(lsfc, monkeypatch, ndev, overlap):
     from fast_solver_lippmann_schwinger_amd.distributed import MultiDeviceFastM3D
+    if ndev in (2, 8):
+        monkeypatch.setenv("LSFC_DIST_COMPUTE_STREAMS", "2")    # odd chunks on a second compute stream per rank (opt-in form)
     monkeypatch.setenv("LSFC_DIST_OVERLAP", overlap)
     c = cases.case_3d("gv32k10")
     Mo, b, n = c["M"], c["b"], c["n"]
